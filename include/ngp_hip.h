@@ -1,0 +1,296 @@
+/*
+ * ngp_hip.h — C ABI of libngp_hip.so, the MI355X (gfx950) instant-NGP hot path.
+ *
+ * This is the drop-in boundary for the reference's native extension surface:
+ *   - `vren` (pybind11 module, /root/reference/models/csrc/binding.cpp:323-342,
+ *     prototypes in models/csrc/include/utils.h:10-170), and
+ *   - the tiny-cuda-nn objects the reference's field uses
+ *     (models/networks.py:40-163: Grid/Hash encoding, SphericalHarmonics,
+ *     CutlassMLP), plus the optimizer step the trainer runs (train.py:244).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major data unless a
+ *     parameter is explicitly documented as host memory;
+ *   - the caller owns every buffer (allocated on the stream it passes in);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - return 0 on success, a negative NGP_E* code on failure; never throws,
+ *     never allocates, never synchronises the device, no hidden global state
+ *     (safe to capture into a hipGraph);
+ *   - all floating point is fp32, indices are int32/int64 as the reference's.
+ *
+ * Each entry point cites the reference interface it replaces.
+ */
+#ifndef NGP_HIP_H
+#define NGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGP_OK 0
+#define NGP_EINVAL (-22)   /* bad argument (null pointer, unsupported size) */
+#define NGP_ELAUNCH (-5)   /* hipLaunch reported an error */
+
+#define NGP_MAX_LEVELS 32
+
+/* Activation codes shared by the MLP entry points. */
+enum ngp_activation {
+    NGP_ACT_NONE = 0,
+    NGP_ACT_RELU = 1,
+    NGP_ACT_SIGMOID = 2,
+    NGP_ACT_SOFTPLUS = 3, /* torch.nn.Softplus(beta=1, threshold=20), models/networks.py:56,59 */
+    NGP_ACT_EXP = 4
+};
+
+/* library / build identification: returns a static string "ngp_hip <ver> gfx950". */
+const char* ngp_version(void);
+
+/* ------------------------------------------------------------------------
+ * R1  ray / AABB and ray / sphere intersection
+ * replaces vren.ray_aabb_intersect  (binding.cpp:4-16,  intersection.cu:25-100)
+ *          vren.ray_sphere_intersect (binding.cpp:19-31, intersection.cu:124-197)
+ * outputs: hit_cnt (n_rays) i32 = number of voxels hit (not capped),
+ *          hits_t (n_rays,max_hits,2) f32, hits_idx (n_rays,max_hits) i64,
+ *          both sorted ascending by t1 with unused slots (-1) first, exactly as
+ *          the reference's torch::sort + gather leaves them.
+ * ---------------------------------------------------------------------- */
+int ngp_ray_aabb_intersect(const float* rays_o, const float* rays_d,
+                           const float* centers, const float* half_sizes,
+                           int n_rays, int n_voxels, int max_hits,
+                           int32_t* hit_cnt, float* hits_t, int64_t* hits_idx,
+                           void* stream);
+
+int ngp_ray_sphere_intersect(const float* rays_o, const float* rays_d,
+                             const float* centers, const float* radii,
+                             int n_rays, int n_spheres, int max_hits,
+                             int32_t* hit_cnt, float* hits_t, int64_t* hits_idx,
+                             void* stream);
+
+/* render() pre-amble (models/rendering.py:30): t1 in [0,near) -> near, in place on
+ * hits_t (n_rays, max_hits, 2) slot 0. */
+int ngp_clamp_near(float* hits_t, int n_rays, int max_hits, float near_distance, void* stream);
+
+/* ------------------------------------------------------------------------
+ * O1  occupancy-grid helpers
+ * replaces vren.morton3D / morton3D_invert / packbits
+ *          (binding.cpp:74-101, raymarching.cu:35-161)
+ * ---------------------------------------------------------------------- */
+int ngp_morton3D(const int32_t* coords, int n, int32_t* indices, void* stream);
+int ngp_morton3D_invert(const int32_t* indices, int n, int32_t* coords, void* stream);
+int ngp_packbits(const float* density_grid, int n_bytes, float threshold,
+                 uint8_t* density_bitfield, void* stream);
+
+/* NGP.update_density_grid's point generation + EMA, fused (models/networks.py:388-403):
+ * xyzs_w[i] = (coords[i]/(G-1)*2-1)*(s-s/G) + (noise[i]*2-1)*s/G  (noise in [0,1))   */
+int ngp_grid_cell_points(const int32_t* coords, const float* noise, int n, int grid_size,
+                         float s, float* xyzs_w, void* stream);
+/* grid = grid<0 ? grid : max(grid*decay, tmp)  (networks.py:400-403), n = K*G^3 */
+int ngp_density_grid_ema(float* density_grid, const float* density_grid_tmp, int n,
+                         float decay, void* stream);
+
+/* ------------------------------------------------------------------------
+ * R3  training ray marcher
+ * replaces vren.raymarching_train (binding.cpp:104-131, raymarching.cu:166-332)
+ *
+ * Three launches: DDA count pass (one lane per ray, sample t's parked in
+ * `t_scratch`), single-workgroup exclusive scan (writes rays_a and counter),
+ * wave-per-ray expansion (coalesced xyzs/dirs/deltas/ts writes).
+ * rays_a rows are in ray order with start indices monotone (a legal instance of
+ * the reference's atomic order, raymarching.cu:237-241).
+ *
+ * t_scratch: (n_rays*max_samples) f32 workspace; ray_counts: (n_rays) i32 workspace.
+ * xyzs/dirs: capacity `sample_capacity` rows (the reference allocates
+ * n_rays*max_samples); rows >= counter[0] are left untouched unless zero_tail!=0,
+ * in which case they are zero-filled like the reference's torch::zeros.
+ * counter: (2) i32 -> {total samples, n_rays}.
+ * ---------------------------------------------------------------------- */
+int ngp_raymarching_train(const float* rays_o, const float* rays_d, const float* hits_t /* (n_rays,2) */,
+                          const uint8_t* density_bitfield, int cascades, float scale,
+                          float exp_step_factor, const float* noise, int grid_size,
+                          int max_samples, int n_rays,
+                          float* t_scratch, int32_t* ray_counts,
+                          int64_t* rays_a, float* xyzs, float* dirs, float* deltas, float* ts,
+                          int32_t* counter, int64_t sample_capacity, int zero_tail,
+                          void* stream);
+
+/* ------------------------------------------------------------------------
+ * T1  test-time marcher / compositor
+ * replaces vren.raymarching_test (binding.cpp:134-163, raymarching.cu:335-454)
+ *          vren.composite_test_fw (binding.cpp:262-320, volumerendering.cu:314-423)
+ * hits_t (n_rays_total,2) is updated in place; outputs are (n_alive,N_samples,.)
+ * and must be zero-initialised by the caller (reference: torch::zeros).
+ * ---------------------------------------------------------------------- */
+int ngp_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t,
+                         const int64_t* alive_indices, const uint8_t* density_bitfield,
+                         int cascades, float scale, float exp_step_factor, int grid_size,
+                         int max_samples, int n_samples, int n_alive,
+                         float* xyzs, float* dirs, float* deltas, float* ts,
+                         int32_t* n_eff_samples, void* stream);
+
+int ngp_composite_test_fw(const float* sigmas, const float* rgbs, const float* normals,
+                          const float* normals_raw, const float* sems, const float* deltas,
+                          const float* ts, const float* hits_t, int64_t* alive_indices,
+                          float T_threshold, int classes, const int32_t* n_eff_samples,
+                          int n_alive, int n_samples,
+                          float* opacity, float* depth, float* rgb, float* normal,
+                          float* normal_raw, float* sem, void* stream);
+
+/* ------------------------------------------------------------------------
+ * V1/V2  training compositor
+ * replaces vren.composite_alpha_fw (binding.cpp:166-180, volumerendering.cu:5-63)
+ *          vren.composite_train_fw (binding.cpp:183-208, volumerendering.cu:65-164)
+ *          vren.composite_train_bw (binding.cpp:211-259, volumerendering.cu:167-311)
+ * One 32-lane half-wave per rays_a row, segmented transmittance scan, early stop
+ * at T <= T_threshold.  Every per-sample output row of the ray is written (zeros
+ * past the stop), so callers need not pre-zero per-sample outputs; per-ray
+ * outputs are written for every rays_a row.
+ * ---------------------------------------------------------------------- */
+int ngp_composite_alpha_fw(const float* sigmas, const float* deltas, const int64_t* rays_a,
+                           float T_threshold, int n_rays, float* alphas, float* ws, void* stream);
+
+int ngp_composite_train_fw(const float* sigmas, const float* rgbs, const float* normals_pred,
+                           const float* sems, const float* deltas, const float* ts,
+                           const int64_t* rays_a, float T_threshold, int classes, int n_rays,
+                           int64_t* total_samples, float* opacity, float* depth, float* rgb,
+                           float* normal_pred, float* sem, float* ws, void* stream);
+
+int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb,
+                           const float* dL_dnormal_pred, const float* dL_dsem, const float* dL_dws,
+                           const float* sigmas, const float* rgbs, const float* normals_pred,
+                           const float* ws, const float* deltas, const float* ts,
+                           const int64_t* rays_a, const float* opacity, const float* depth,
+                           const float* rgb, const float* normal_pred,
+                           float T_threshold, int classes, int n_rays,
+                           float* dL_dsigmas, float* dL_drgbs, float* dL_dnormals_pred,
+                           float* dL_dsems, void* stream);
+
+/* ------------------------------------------------------------------------
+ * V3  Ref-NeRF normal regularisers
+ * replaces vren.composite_refloss_fw/bw (binding.cpp, ref_loss.cu:4-175)
+ * ---------------------------------------------------------------------- */
+int ngp_composite_refloss_fw(const float* sigmas, const float* normals_diff, const float* normals_ori,
+                             const float* deltas, const float* ts, const int64_t* rays_a,
+                             float T_threshold, int n_rays, float* loss_o, float* loss_p,
+                             void* stream);
+
+int ngp_composite_refloss_bw(const float* dL_dloss_o, const float* dL_dloss_p,
+                             const float* sigmas, const float* normals_diff, const float* normals_ori,
+                             const float* deltas, const float* ts, const int64_t* rays_a,
+                             const float* loss_o, const float* loss_p, float T_threshold, int n_rays,
+                             float* dL_dsigmas, float* dL_dnormals_diff, float* dL_dnormals_ori,
+                             void* stream);
+
+/* ------------------------------------------------------------------------
+ * D1  distortion loss
+ * replaces vren.distortion_loss_fw/bw (binding.cpp, losses.cu:8-173)
+ * ---------------------------------------------------------------------- */
+int ngp_distortion_loss_fw(const float* ws, const float* deltas, const float* ts,
+                           const int64_t* rays_a, int n_rays,
+                           float* loss, float* ws_inclusive_scan, float* wts_inclusive_scan,
+                           void* stream);
+
+int ngp_distortion_loss_bw(const float* dL_dloss, const float* ws_inclusive_scan,
+                           const float* wts_inclusive_scan, const float* ws, const float* deltas,
+                           const float* ts, const int64_t* rays_a, int n_rays,
+                           float* dL_dws, void* stream);
+
+/* ------------------------------------------------------------------------
+ * R4  torch_scatter.segment_csr(src, indptr) with sum reduction
+ * (custom_functions.py:110-112).  src (n_rows, width), indptr (n_seg+1) i64.
+ * ---------------------------------------------------------------------- */
+int ngp_segment_csr_sum(const float* src, const int64_t* indptr, int n_seg, int width,
+                        float* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * H1-H4  multiresolution hash grid (tcnn.Encoding otype Grid/HashGrid,
+ * models/networks.py:40-52,67-76; semantics SURVEY.md Appendix B)
+ * 3-D inputs in [0,1], linear interpolation, F in {1,2,4,8}.
+ * ---------------------------------------------------------------------- */
+typedef struct ngp_grid_desc {
+    uint32_t n_levels;
+    uint32_t n_features;            /* F */
+    uint32_t offsets[NGP_MAX_LEVELS + 1]; /* in table rows (F floats each) */
+    uint32_t resolution[NGP_MAX_LEVELS];
+    float    scale[NGP_MAX_LEVELS];
+} ngp_grid_desc;
+
+/* Host-side helper: fills `desc` from the tcnn config keys; returns the number of
+ * parameters (floats) of the table, or a negative error. */
+int64_t ngp_grid_layout(int n_levels, int n_features, int log2_hashmap_size,
+                        int base_resolution, double per_level_scale, ngp_grid_desc* desc);
+
+/* y (n, L*F) = encode(x (n,3)); */
+int ngp_grid_fwd(const ngp_grid_desc* desc /* host */, const float* table, const float* x,
+                 int64_t n, float* y, void* stream);
+
+/* dtable[(off+idx)*F+f] += w * dL_dy  (atomic fp32 scatter-add; caller zeroes dtable) */
+int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* dL_dy,
+                       int64_t n, float* dtable, void* stream);
+
+/* dL_dx (n,3) = sum_l d enc_l / dx . dL_dy_l */
+int ngp_grid_bwd_input(const ngp_grid_desc* desc, const float* table, const float* x,
+                       const float* dL_dy, int64_t n, float* dL_dx, void* stream);
+
+/* double backward of ngp_grid_bwd_input: given dL_ddLdx (n,3) (gradient flowing into
+ * dL_dx), accumulates dtable (atomic) and writes dL_ddLdy (n, L*F).  Either output
+ * may be NULL. */
+int ngp_grid_bwd_bwd_input(const ngp_grid_desc* desc, const float* table, const float* x,
+                           const float* dL_dy, const float* dL_ddLdx, int64_t n,
+                           float* dtable, float* dL_ddLdy, void* stream);
+
+/* ------------------------------------------------------------------------
+ * H5  spherical harmonics (tcnn.Encoding otype SphericalHarmonics, degree 1..4,
+ * networks.py:78-85,128-135).  x (n,3) in [0,1] -> y (n, degree^2).
+ * ---------------------------------------------------------------------- */
+int ngp_sh_fwd(const float* x, int64_t n, int degree, float* y, void* stream);
+int ngp_sh_bwd_input(const float* x, const float* dL_dy, int64_t n, int degree,
+                     float* dL_dx, void* stream);
+
+/* ------------------------------------------------------------------------
+ * M1-M4  small MLP layers on f32 MFMA (v_mfma_f32_32x32x2_f32)
+ * replaces tcnn.Network(CutlassMLP) (networks.py:89-163) and the torch xyz_net
+ * (networks.py:54-58).  Weights are (n_out, n_in) row-major (tcnn / nn.Linear).
+ *
+ * ngp_linear_fwd : y (n, n_out) = act(x (n, n_in) . W^T + b)      b may be NULL
+ * ngp_linear_bwd_input : dx (n, n_in) = dz (n, n_out) . W
+ * ngp_linear_bwd_weight: dW (n_out, n_in) += dz^T . x ; db (n_out) += sum dz
+ *                        (atomic split-K over samples; caller zeroes dW/db)
+ * ngp_act_bwd : dz = dy * act'(.)  given the layer OUTPUT y (post-activation)
+ *               for ReLU/Sigmoid/Exp, or the pre-activation for Softplus.
+ * ldx/ldy/lddz/lddx are row strides in floats (>= the logical width).
+ * ---------------------------------------------------------------------- */
+int ngp_linear_fwd(const float* x, int64_t ldx, const float* W, const float* b,
+                   int64_t n, int n_in, int n_out, int activation,
+                   float* y, int64_t ldy, float* z_pre /* optional (n,n_out) pre-activation, may be NULL */,
+                   void* stream);
+
+int ngp_linear_bwd_input(const float* dz, int64_t lddz, const float* W,
+                         int64_t n, int n_in, int n_out, float* dx, int64_t lddx, void* stream);
+
+int ngp_linear_bwd_weight(const float* dz, int64_t lddz, const float* x, int64_t ldx,
+                          int64_t n, int n_in, int n_out, float* dW, float* db /* may be NULL */,
+                          void* stream);
+
+int ngp_act_bwd(const float* dy, const float* y_or_z, int64_t count, int activation,
+                float* dz, void* stream);
+
+/* ------------------------------------------------------------------------
+ * fused Adam step (torch.optim.Adam(eps=1e-8) semantics, train.py:244) over one
+ * flat fp32 tensor; optionally scales the gradient first (grad clipping /
+ * 1/world_size) and zeroes it afterwards.
+ * step is the 1-based step count.
+ * ---------------------------------------------------------------------- */
+int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int64_t step, const float* grad_scale /* device scalar or NULL */,
+                  int zero_grad, void* stream);
+
+/* sum of squares of a flat tensor accumulated into *out (device scalar; caller zeroes) */
+int ngp_sumsq(const float* x, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGP_HIP_H */

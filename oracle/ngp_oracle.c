@@ -1,0 +1,789 @@
+/*
+ * ngp_oracle.c — CPU restatement of the reference's algorithm for the instant-NGP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under instant-ngp-pp_amd/ may link, load or call
+ * this file; it exists so that tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg can check (and time) the HIP path against an independent
+ * scalar implementation.
+ *
+ * Pinning: the compositing maths is pinned against golden vectors generated from
+ * the reference's own importable pure-torch code (raw2outputs, sample_pdf,
+ * rendering_noCUDA.render; tests/golden/make_golden.py).  The `vren` CUDA kernels
+ * cannot be built or run in this environment (no nvcc / no GPU here) and the
+ * reference has no tests, so the ray marcher, distortion/ref losses and the
+ * tiny-cuda-nn parts (hash grid, SH) are restated from the sources/semantics cited
+ * at each function and pinned only by known-answer tests: PARITY UNPINNED for
+ * those rows.
+ *
+ * All arithmetic is fp32 with the reference's expression order; compile with
+ * -ffp-contract=off so that no FMA contraction changes results.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SQRT3F 1.73205080757f
+
+static inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+static inline float sgnf(float x) { return copysignf(1.0f, x); }
+
+/* ---- intersection.cu:5-22 (slab test) + 25-56 (record) + 94-97 (sort) -------------- */
+static void sort_hits(float* t, int64_t* idx, int max_hits)
+{
+    /* ascending on t1, unused (-1) slots first; insertion sort is stable */
+    for (int i = 1; i < max_hits; i++) {
+        float a = t[2 * i], b = t[2 * i + 1];
+        int64_t v = idx[i];
+        int j = i - 1;
+        while (j >= 0 && t[2 * j] > a) {
+            t[2 * j + 2] = t[2 * j]; t[2 * j + 3] = t[2 * j + 1]; idx[j + 1] = idx[j];
+            j--;
+        }
+        t[2 * j + 2] = a; t[2 * j + 3] = b; idx[j + 1] = v;
+    }
+}
+
+int ngp_cpu_ray_aabb_intersect(const float* rays_o, const float* rays_d, const float* centers,
+                               const float* half_sizes, int n_rays, int n_voxels, int max_hits,
+                               int32_t* hit_cnt, float* hits_t, int64_t* hits_idx)
+{
+    #pragma omp parallel for schedule(static)
+    for (int r = 0; r < n_rays; r++) {
+        float* ht = hits_t + (size_t)r * max_hits * 2;
+        int64_t* hi = hits_idx + (size_t)r * max_hits;
+        for (int k = 0; k < max_hits; k++) { ht[2 * k] = ht[2 * k + 1] = -1.0f; hi[k] = -1; }
+        int cnt = 0;
+        const float ix = 1.0f / rays_d[3 * r], iy = 1.0f / rays_d[3 * r + 1], iz = 1.0f / rays_d[3 * r + 2];
+        const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
+        for (int v = 0; v < n_voxels; v++) {
+            const float* c = centers + 3 * v; const float* h = half_sizes + 3 * v;
+            float ax = (c[0] - h[0] - ox) * ix, bx = (c[0] + h[0] - ox) * ix;
+            float ay = (c[1] - h[1] - oy) * iy, by = (c[1] + h[1] - oy) * iy;
+            float az = (c[2] - h[2] - oz) * iz, bz = (c[2] + h[2] - oz) * iz;
+            float t1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+            float t2 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            if (t1 > t2) { t1 = -1.0f; t2 = -1.0f; }
+            if (t2 > 0) {
+                if (cnt < max_hits) { ht[2 * cnt] = fmaxf(t1, 0.0f); ht[2 * cnt + 1] = t2; hi[cnt] = v; }
+                cnt++;
+            }
+        }
+        hit_cnt[r] = cnt;
+        sort_hits(ht, hi, max_hits);
+    }
+    return 0;
+}
+
+/* ---- intersection.cu:103-153 ------------------------------------------------------- */
+int ngp_cpu_ray_sphere_intersect(const float* rays_o, const float* rays_d, const float* centers,
+                                 const float* radii, int n_rays, int n_spheres, int max_hits,
+                                 int32_t* hit_cnt, float* hits_t, int64_t* hits_idx)
+{
+    for (int r = 0; r < n_rays; r++) {
+        float* ht = hits_t + (size_t)r * max_hits * 2;
+        int64_t* hi = hits_idx + (size_t)r * max_hits;
+        for (int k = 0; k < max_hits; k++) { ht[2 * k] = ht[2 * k + 1] = -1.0f; hi[k] = -1; }
+        int cnt = 0;
+        const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
+        for (int s = 0; s < n_spheres; s++) {
+            float cx = rays_o[3 * r] - centers[3 * s], cy = rays_o[3 * r + 1] - centers[3 * s + 1],
+                  cz = rays_o[3 * r + 2] - centers[3 * s + 2];
+            float a = dx * dx + dy * dy + dz * dz;
+            float half_b = dx * cx + dy * cy + dz * cz;
+            float c = cx * cx + cy * cy + cz * cz - radii[s] * radii[s];
+            float disc = half_b * half_b - a * c;
+            float t1 = -1.0f, t2 = -1.0f;
+            if (!(disc < 0)) {
+                float sq = sqrtf(disc);
+                t1 = (-half_b - sq) / a; t2 = (-half_b + sq) / a;
+            }
+            if (t2 > 0) {
+                if (cnt < max_hits) { ht[2 * cnt] = fmaxf(t1, 0.0f); ht[2 * cnt + 1] = t2; hi[cnt] = s; }
+                cnt++;
+            }
+        }
+        hit_cnt[r] = cnt;
+        sort_hits(ht, hi, max_hits);
+    }
+    return 0;
+}
+
+/* ---- raymarching.cu:35-60 (bit interleave) ------------------------------------------ */
+static inline uint32_t spread3(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+static inline uint32_t morton_enc(uint32_t x, uint32_t y, uint32_t z)
+{
+    return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+}
+static inline uint32_t compact3(uint32_t x)
+{
+    x &= 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+int ngp_cpu_morton3D(const int32_t* coords, int n, int32_t* indices)
+{
+    for (int i = 0; i < n; i++)
+        indices[i] = (int32_t)morton_enc((uint32_t)coords[3 * i], (uint32_t)coords[3 * i + 1], (uint32_t)coords[3 * i + 2]);
+    return 0;
+}
+int ngp_cpu_morton3D_invert(const int32_t* indices, int n, int32_t* coords)
+{
+    for (int i = 0; i < n; i++) {
+        int32_t v = indices[i]; /* arithmetic shifts of the signed value, as the reference */
+        coords[3 * i] = (int32_t)compact3((uint32_t)(v >> 0));
+        coords[3 * i + 1] = (int32_t)compact3((uint32_t)(v >> 1));
+        coords[3 * i + 2] = (int32_t)compact3((uint32_t)(v >> 2));
+    }
+    return 0;
+}
+
+/* ---- raymarching.cu:122-141 ---------------------------------------------------------- */
+int ngp_cpu_packbits(const float* grid, int n_bytes, float thr, uint8_t* bits)
+{
+    for (int n = 0; n < n_bytes; n++) {
+        uint8_t b = 0;
+        for (int i = 0; i < 8; i++) if (grid[8 * (size_t)n + i] > thr) b |= (uint8_t)(1u << i);
+        bits[n] = b;
+    }
+    return 0;
+}
+
+/* networks.py:388-394 cell sample points; 400-403 EMA */
+int ngp_cpu_grid_cell_points(const int32_t* coords, const float* noise, int n, int G, float s, float* out)
+{
+    const float hgs = s / G;
+    for (int i = 0; i < 3 * n; i++) {
+        float c = (float)coords[i] / (float)(G - 1) * 2 - 1;
+        out[i] = c * (s - hgs) + (noise[i] * 2 - 1) * hgs;
+    }
+    return 0;
+}
+int ngp_cpu_density_grid_ema(float* grid, const float* tmp, int n, float decay)
+{
+    for (int i = 0; i < n; i++) if (!(grid[i] < 0)) grid[i] = fmaxf(grid[i] * decay, tmp[i]);
+    return 0;
+}
+
+/* ---- raymarching.cu:11-32 step size / mip selection ---------------------------------- */
+static inline float step_dt(float t, float esf, int max_samples, int G, float scale)
+{
+    return clampf(t * esf, SQRT3F / max_samples, SQRT3F * 2 * scale / G);
+}
+static inline int mip_of_pos(float x, float y, float z, int cascades)
+{
+    float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int e; frexpf(mx, &e);
+    int m = e + 1; if (m < 0) m = 0; if (m > cascades - 1) m = cascades - 1;
+    return m;
+}
+static inline int mip_of_dt(float dt, int G, int cascades)
+{
+    int e; frexpf(dt * G, &e);
+    int m = e; if (m < 0) m = 0; if (m > cascades - 1) m = cascades - 1;
+    return m;
+}
+
+typedef struct {
+    float ox, oy, oz, dx, dy, dz, idx_, idy_, idz_;
+    const uint8_t* bits; int cascades, G; uint32_t G3; float scale, esf, Ginv; int max_samples;
+    float dt_scale; /* the `scale` handed to calc_dt (the test marcher passes `cascades`) */
+} march_ctx;
+
+/* One DDA decision at parameter t (raymarching.cu:205-233): returns 1 if the cell is
+ * occupied (and leaves *t alone, *dt_out = step), else advances *t past the cell. */
+static inline int march_probe(const march_ctx* c, float* t, float* x, float* y, float* z, float* dt_out)
+{
+    const float tt = *t;
+    *x = c->ox + tt * c->dx; *y = c->oy + tt * c->dy; *z = c->oz + tt * c->dz;
+    const float dt = step_dt(tt, c->esf, c->max_samples, c->G, c->dt_scale);
+    int mip = mip_of_pos(*x, *y, *z, c->cascades);
+    int m2 = mip_of_dt(dt, c->G, c->cascades);
+    if (m2 > mip) mip = m2;
+    const float bound = fminf(scalbnf(1.0f, mip - 1), c->scale);
+    const float binv = 1 / bound;
+    const int nx = (int)clampf(0.5f * (*x * binv + 1) * c->G, 0.0f, c->G - 1.0f);
+    const int ny = (int)clampf(0.5f * (*y * binv + 1) * c->G, 0.0f, c->G - 1.0f);
+    const int nz = (int)clampf(0.5f * (*z * binv + 1) * c->G, 0.0f, c->G - 1.0f);
+    const uint32_t idx = (uint32_t)mip * c->G3 + morton_enc((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+    const int occ = c->bits[idx / 8] & (1 << (idx % 8));
+    *dt_out = dt;
+    if (occ) return 1;
+    const float tx = (((nx + 0.5f + 0.5f * sgnf(c->dx)) * c->Ginv * 2 - 1) * bound - *x) * c->idx_;
+    const float ty = (((ny + 0.5f + 0.5f * sgnf(c->dy)) * c->Ginv * 2 - 1) * bound - *y) * c->idy_;
+    const float tz = (((nz + 0.5f + 0.5f * sgnf(c->dz)) * c->Ginv * 2 - 1) * bound - *z) * c->idz_;
+    const float t_target = tt + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    float tn = tt;
+    do { tn += step_dt(tn, c->esf, c->max_samples, c->G, c->dt_scale); } while (tn < t_target);
+    *t = tn;
+    return 0;
+}
+
+static void march_ctx_init(march_ctx* c, const float* o, const float* d, const uint8_t* bits, int cascades,
+                           float scale, float esf, int G, int max_samples, float dt_scale)
+{
+    c->ox = o[0]; c->oy = o[1]; c->oz = o[2]; c->dx = d[0]; c->dy = d[1]; c->dz = d[2];
+    c->idx_ = 1.0f / d[0]; c->idy_ = 1.0f / d[1]; c->idz_ = 1.0f / d[2];
+    c->bits = bits; c->cascades = cascades; c->G = G; c->G3 = (uint32_t)G * G * G;
+    c->scale = scale; c->esf = esf; c->Ginv = 1.0f / G; c->max_samples = max_samples; c->dt_scale = dt_scale;
+}
+
+/* ---- raymarching.cu:166-280.  Rows of rays_a are emitted in ray order (one legal
+ * outcome of the reference's atomicAdd ordering). ------------------------------------- */
+int ngp_cpu_raymarching_train(const float* rays_o, const float* rays_d, const float* hits_t,
+                              const uint8_t* bits, int cascades, float scale, float esf,
+                              const float* noise, int G, int max_samples, int n_rays,
+                              int64_t* rays_a, float* xyzs, float* dirs, float* deltas, float* ts,
+                              int32_t* counter)
+{
+    int32_t* counts = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_rays > 0 ? n_rays : 1));
+    float* t1s = (float*)malloc(sizeof(float) * (size_t)(n_rays > 0 ? n_rays : 1));
+    if (!counts || !t1s) { free(counts); free(t1s); return -12; }
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (int r = 0; r < n_rays; r++) {
+        march_ctx c; march_ctx_init(&c, rays_o + 3 * r, rays_d + 3 * r, bits, cascades, scale, esf, G, max_samples, scale);
+        float t1 = hits_t[2 * r], t2 = hits_t[2 * r + 1];
+        if (t1 >= 0) { const float dt = step_dt(t1, esf, max_samples, G, scale); t1 += dt * noise[r]; }
+        float t = t1; int n = 0;
+        while (0 <= t && t < t2 && n < max_samples) {
+            float x, y, z, dt;
+            if (march_probe(&c, &t, &x, &y, &z, &dt)) { t += dt; n++; }
+        }
+        counts[r] = n; t1s[r] = t1;
+    }
+    int64_t start = 0;
+    for (int r = 0; r < n_rays; r++) {
+        rays_a[3 * r] = r; rays_a[3 * r + 1] = start; rays_a[3 * r + 2] = counts[r];
+        start += counts[r];
+    }
+    counter[0] = (int32_t)start; counter[1] = n_rays;
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (int r = 0; r < n_rays; r++) {
+        march_ctx c; march_ctx_init(&c, rays_o + 3 * r, rays_d + 3 * r, bits, cascades, scale, esf, G, max_samples, scale);
+        const float t2 = hits_t[2 * r + 1];
+        float t = t1s[r]; int k = 0; const int n = counts[r]; const int64_t s0 = rays_a[3 * r + 1];
+        while (t < t2 && k < n) {
+            float x, y, z, dt;
+            const float tcur = t;
+            if (march_probe(&c, &t, &x, &y, &z, &dt)) {
+                const int64_t s = s0 + k;
+                xyzs[3 * s] = x; xyzs[3 * s + 1] = y; xyzs[3 * s + 2] = z;
+                dirs[3 * s] = c.dx; dirs[3 * s + 1] = c.dy; dirs[3 * s + 2] = c.dz;
+                ts[s] = tcur; deltas[s] = dt;
+                t += dt; k++;
+            }
+        }
+    }
+    free(counts); free(t1s);
+    return 0;
+}
+
+/* ---- raymarching.cu:335-404 (note calc_dt receives `cascades` as scale: 370,399) ----- */
+int ngp_cpu_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t,
+                             const int64_t* alive, const uint8_t* bits, int cascades, float scale,
+                             float esf, int G, int max_samples, int n_samples, int n_alive,
+                             float* xyzs, float* dirs, float* deltas, float* ts, int32_t* n_eff)
+{
+    for (int n = 0; n < n_alive; n++) {
+        const int64_t r = alive[n];
+        march_ctx c; march_ctx_init(&c, rays_o + 3 * r, rays_d + 3 * r, bits, cascades, scale, esf, G, max_samples, (float)cascades);
+        float t = hits_t[2 * r]; const float t2 = hits_t[2 * r + 1];
+        int s = 0;
+        while (t < t2 && s < n_samples) {
+            float x, y, z, dt; const float tcur = t;
+            if (march_probe(&c, &t, &x, &y, &z, &dt)) {
+                const size_t o = (size_t)n * n_samples + s;
+                xyzs[3 * o] = x; xyzs[3 * o + 1] = y; xyzs[3 * o + 2] = z;
+                dirs[3 * o] = c.dx; dirs[3 * o + 1] = c.dy; dirs[3 * o + 2] = c.dz;
+                ts[o] = tcur; deltas[o] = dt;
+                t += dt; hits_t[2 * r] = t; s++;
+            }
+        }
+        n_eff[n] = s;
+    }
+    return 0;
+}
+
+/* ---- volumerendering.cu:5-34 ----------------------------------------------------------- */
+int ngp_cpu_composite_alpha_fw(const float* sigmas, const float* deltas, const int64_t* rays_a,
+                               float T_thr, int n_rays, float* alphas, float* ws)
+{
+    for (int n = 0; n < n_rays; n++) {
+        const int64_t start = rays_a[3 * n + 1], N = rays_a[3 * n + 2];
+        float T = 1.0f;
+        for (int64_t k = 0; k < N; k++) {
+            const int64_t s = start + k;
+            const float a = 1.0f - expf(-sigmas[s] * deltas[s]);
+            alphas[s] = a; ws[s] = a * T; T *= 1.0f - a;
+            if (T <= T_thr) break;
+        }
+    }
+    return 0;
+}
+
+/* ---- volumerendering.cu:84-114.  All outputs must be zero on entry. -------------------- */
+int ngp_cpu_composite_train_fw(const float* sigmas, const float* rgbs, const float* normals_pred,
+                               const float* sems, const float* deltas, const float* ts,
+                               const int64_t* rays_a, float T_thr, int classes, int n_rays,
+                               int64_t* total_samples, float* opacity, float* depth, float* rgb,
+                               float* normal_pred, float* sem, float* ws)
+{
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (int n = 0; n < n_rays; n++) {
+        const int64_t ray = rays_a[3 * n], start = rays_a[3 * n + 1], N = rays_a[3 * n + 2];
+        int64_t k = 0; float T = 1.0f;
+        while (k < N) {
+            const int64_t s = start + k;
+            const float a = 1.0f - expf(-sigmas[s] * deltas[s]);
+            const float w = a * T;
+            for (int c = 0; c < 3; c++) rgb[3 * ray + c] += w * rgbs[3 * s + c];
+            for (int c = 0; c < 3; c++) normal_pred[3 * ray + c] += w * normals_pred[3 * s + c];
+            depth[ray] += w * ts[s];
+            for (int c = 0; c < classes; c++) sem[(size_t)ray * classes + c] += w * sems[(size_t)s * classes + c];
+            opacity[ray] += w;
+            ws[s] = w;
+            T *= 1.0f - a;
+            if (T <= T_thr) break;
+            k++;
+        }
+        total_samples[ray] = k;
+    }
+    return 0;
+}
+
+/* ---- volumerendering.cu:193-245.  Per-sample outputs must be zero on entry. ------------ */
+int ngp_cpu_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb,
+                               const float* dL_dnormal_pred, const float* dL_dsem, const float* dL_dws,
+                               const float* sigmas, const float* rgbs, const float* normals_pred,
+                               const float* ws, const float* deltas, const float* ts,
+                               const int64_t* rays_a, const float* opacity, const float* depth,
+                               const float* rgb, const float* normal_pred, float T_thr, int classes,
+                               int n_rays, float* dL_dsigmas, float* dL_drgbs,
+                               float* dL_dnormals_pred, float* dL_dsems)
+{
+    (void)normals_pred; (void)normal_pred;
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (int n = 0; n < n_rays; n++) {
+        const int64_t ray = rays_a[3 * n], start = rays_a[3 * n + 1], N = rays_a[3 * n + 2];
+        if (N <= 0) continue; /* the reference reads start-1 here (volumerendering.cu:210); guarded */
+        float* pref = (float*)malloc(sizeof(float) * (size_t)N);
+        float acc = 0.0f;
+        for (int64_t k = 0; k < N; k++) { acc = (k == 0) ? dL_dws[start] * ws[start] : acc + dL_dws[start + k] * ws[start + k]; pref[k] = acc; }
+        const float tot = pref[N - 1];
+        const float R = rgb[3 * ray], G = rgb[3 * ray + 1], B = rgb[3 * ray + 2];
+        const float O = opacity[ray], D = depth[ray];
+        float T = 1.0f, r = 0, g = 0, b = 0, d = 0;
+        for (int64_t k = 0; k < N; k++) {
+            const int64_t s = start + k;
+            const float a = 1.0f - expf(-sigmas[s] * deltas[s]);
+            const float w = a * T;
+            r += w * rgbs[3 * s]; g += w * rgbs[3 * s + 1]; b += w * rgbs[3 * s + 2];
+            d += w * ts[s];
+            T *= 1.0f - a;
+            for (int c = 0; c < 3; c++) dL_drgbs[3 * s + c] = dL_drgb[3 * ray + c] * w;
+            for (int c = 0; c < 3; c++) dL_dnormals_pred[3 * s + c] = dL_dnormal_pred[3 * ray + c] * w;
+            for (int c = 0; c < classes; c++) dL_dsems[(size_t)s * classes + c] = dL_dsem[(size_t)ray * classes + c] * w;
+            dL_dsigmas[s] = deltas[s] * (
+                dL_drgb[3 * ray] * (rgbs[3 * s] * T - (R - r)) +
+                dL_drgb[3 * ray + 1] * (rgbs[3 * s + 1] * T - (G - g)) +
+                dL_drgb[3 * ray + 2] * (rgbs[3 * s + 2] * T - (B - b)) +
+                dL_dopacity[ray] * (1 - O) +
+                dL_ddepth[ray] * (ts[s] * T - (D - d)) +
+                T * dL_dws[s] - (tot - pref[k]));
+            if (T <= T_thr) break;
+        }
+        free(pref);
+    }
+    return 0;
+}
+
+/* ---- volumerendering.cu:335-373 -------------------------------------------------------- */
+int ngp_cpu_composite_test_fw(const float* sigmas, const float* rgbs, const float* normals,
+                              const float* normals_raw, const float* sems, const float* deltas,
+                              const float* ts, const float* hits_t, int64_t* alive, float T_thr,
+                              int classes, const int32_t* n_eff, int n_alive, int n_samples,
+                              float* opacity, float* depth, float* rgb, float* normal,
+                              float* normal_raw, float* sem)
+{
+    (void)hits_t;
+    for (int n = 0; n < n_alive; n++) {
+        if (n_eff[n] == 0) { alive[n] = -1; continue; }
+        const int64_t r = alive[n];
+        int s = 0; float T = 1 - opacity[r];
+        while (s < n_eff[n]) {
+            const size_t o = (size_t)n * n_samples + s;
+            const float a = 1.0f - expf(-sigmas[o] * deltas[o]);
+            const float w = a * T;
+            for (int c = 0; c < 3; c++) rgb[3 * r + c] += w * rgbs[3 * o + c];
+            depth[r] += w * ts[o];
+            opacity[r] += w;
+            for (int c = 0; c < 3; c++) normal[3 * r + c] += w * normals[3 * o + c];
+            for (int c = 0; c < 3; c++) normal_raw[3 * r + c] += w * normals_raw[3 * o + c];
+            for (int c = 0; c < classes; c++) sem[(size_t)r * classes + c] += w * sems[o * classes + c];
+            T *= 1.0f - a;
+            if (T <= T_thr) { alive[n] = -1; break; }
+            s++;
+        }
+    }
+    return 0;
+}
+
+/* ---- ref_loss.cu:16-37 ------------------------------------------------------------------ */
+int ngp_cpu_composite_refloss_fw(const float* sigmas, const float* normals_diff, const float* normals_ori,
+                                 const float* deltas, const float* ts, const int64_t* rays_a,
+                                 float T_thr, int n_rays, float* loss_o, float* loss_p)
+{
+    (void)ts;
+    for (int n = 0; n < n_rays; n++) {
+        const int64_t ray = rays_a[3 * n], start = rays_a[3 * n + 1], N = rays_a[3 * n + 2];
+        float T = 1.0f;
+        for (int64_t k = 0; k < N; k++) {
+            const int64_t s = start + k;
+            const float a = 1.0f - expf(-sigmas[s] * deltas[s]);
+            const float w = a * T;
+            for (int c = 0; c < 3; c++) loss_p[3 * ray + c] += w * normals_diff[3 * s + c];
+            loss_o[ray] += w * normals_ori[s];
+            T *= 1.0f - a;
+            if (T <= T_thr) break;
+        }
+    }
+    return 0;
+}
+
+/* ---- ref_loss.cu:93-129 ------------------------------------------------------------------ */
+int ngp_cpu_composite_refloss_bw(const float* dL_dloss_o, const float* dL_dloss_p, const float* sigmas,
+                                 const float* normals_diff, const float* normals_ori, const float* deltas,
+                                 const float* ts, const int64_t* rays_a, const float* loss_o,
+                                 const float* loss_p, float T_thr, int n_rays, float* dL_dsigmas,
+                                 float* dL_dnormals_diff, float* dL_dnormals_ori)
+{
+    (void)ts;
+    for (int n = 0; n < n_rays; n++) {
+        const int64_t ray = rays_a[3 * n], start = rays_a[3 * n + 1], N = rays_a[3 * n + 2];
+        const float X = loss_p[3 * ray], Y = loss_p[3 * ray + 1], Z = loss_p[3 * ray + 2], O = loss_o[ray];
+        float T = 1.0f, x = 0, y = 0, z = 0, o = 0;
+        for (int64_t k = 0; k < N; k++) {
+            const int64_t s = start + k;
+            const float a = 1.0f - expf(-sigmas[s] * deltas[s]);
+            const float w = a * T;
+            x += w * normals_diff[3 * s]; y += w * normals_diff[3 * s + 1]; z += w * normals_diff[3 * s + 2];
+            o += w * normals_ori[s];
+            T *= 1.0f - a;
+            for (int c = 0; c < 3; c++) dL_dnormals_diff[3 * s + c] = dL_dloss_p[3 * ray + c] * w;
+            dL_dnormals_ori[s] = dL_dloss_o[ray] * w;
+            dL_dsigmas[s] = deltas[s] * (
+                dL_dloss_p[3 * ray] * (normals_diff[3 * s] * T - (X - x)) +
+                dL_dloss_p[3 * ray + 1] * (normals_diff[3 * s + 1] * T - (Y - y)) +
+                dL_dloss_p[3 * ray + 2] * (normals_diff[3 * s + 2] * T - (Z - z)) +
+                dL_dloss_o[ray] * (normals_ori[s] * T - (O - o)));
+            if (T <= T_thr) break;
+        }
+    }
+    return 0;
+}
+
+/* ---- losses.cu:8-59 + host expression 92-93 ------------------------------------------------ */
+int ngp_cpu_distortion_loss_fw(const float* ws, const float* deltas, const float* ts,
+                               const int64_t* rays_a, int n_rays, float* loss,
+                               float* ws_inc, float* wts_inc)
+{
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (int n = 0; n < n_rays; n++) {
+        const int64_t ray = rays_a[3 * n], start = rays_a[3 * n + 1], N = rays_a[3 * n + 2];
+        float w_acc = 0, wt_acc = 0, L = 0;
+        for (int64_t k = 0; k < N; k++) {
+            const int64_t s = start + k;
+            const float w = ws[s], wt = ws[s] * ts[s];
+            const float w_exc = w_acc, wt_exc = wt_acc;
+            w_acc = (k == 0) ? w : w_acc + w; wt_acc = (k == 0) ? wt : wt_acc + wt;
+            ws_inc[s] = w_acc; wts_inc[s] = wt_acc;
+            const float term = 2 * (wt_acc * w_exc - w_acc * wt_exc) + 1.0f / 3 * w * w * deltas[s];
+            L += term;
+        }
+        loss[ray] = L;
+    }
+    return 0;
+}
+
+/* ---- losses.cu:121-139 ---------------------------------------------------------------------- */
+int ngp_cpu_distortion_loss_bw(const float* dL_dloss, const float* ws_inc, const float* wts_inc,
+                               const float* ws, const float* deltas, const float* ts,
+                               const int64_t* rays_a, int n_rays, float* dL_dws)
+{
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (int n = 0; n < n_rays; n++) {
+        const int64_t ray = rays_a[3 * n], start = rays_a[3 * n + 1], N = rays_a[3 * n + 2];
+        if (N <= 0) continue; /* reference would read start-1 (losses.cu:125-128); guarded */
+        const int64_t end = start + N - 1;
+        const float w_sum = ws_inc[end], wt_sum = wts_inc[end];
+        for (int64_t s = start; s <= end; s++) {
+            float v = dL_dloss[ray] * 2 * (
+                (s == start ? 0.0f : (ts[s] * ws_inc[s - 1] - wts_inc[s - 1])) +
+                (wt_sum - wts_inc[s] - ts[s] * (w_sum - ws_inc[s])));
+            v += dL_dloss[ray] * 2.0f / 3 * ws[s] * deltas[s];
+            dL_dws[s] = v;
+        }
+    }
+    return 0;
+}
+
+/* ---- torch_scatter.segment_csr (sum), custom_functions.py:110-112 --------------------------- */
+int ngp_cpu_segment_csr_sum(const float* src, const int64_t* indptr, int n_seg, int width, float* out)
+{
+    for (int i = 0; i < n_seg; i++)
+        for (int c = 0; c < width; c++) {
+            float a = 0;
+            for (int64_t k = indptr[i]; k < indptr[i + 1]; k++) a += src[(size_t)k * width + c];
+            out[(size_t)i * width + c] = a;
+        }
+    return 0;
+}
+
+/* ==========================================================================================
+ * tiny-cuda-nn semantics (source not in /root/reference; NVlabs/tiny-cuda-nn, version
+ * un-pinned by the reference, README.md:16-28).  Restated from SURVEY.md Appendix B.
+ * ======================================================================================== */
+#define NGP_MAX_LEVELS 32
+typedef struct {
+    uint32_t n_levels, n_features;
+    uint32_t offsets[NGP_MAX_LEVELS + 1];
+    uint32_t resolution[NGP_MAX_LEVELS];
+    float scale[NGP_MAX_LEVELS];
+} grid_desc;
+
+int64_t ngp_cpu_grid_layout(int n_levels, int n_features, int log2_T, int base_res,
+                            double per_level_scale, grid_desc* d)
+{
+    if (n_levels < 1 || n_levels > NGP_MAX_LEVELS) return -22;
+    d->n_levels = (uint32_t)n_levels; d->n_features = (uint32_t)n_features;
+    const float l2 = log2f((float)per_level_scale);
+    uint32_t off = 0;
+    for (int l = 0; l < n_levels; l++) {
+        const float sc = exp2f(l * l2) * base_res - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(sc) + 1;
+        const uint32_t cap = 1u << log2_T;
+        uint64_t dense = (uint64_t)res * res * res;
+        uint32_t p = dense > (uint64_t)0xFFFFFFF0u ? 0xFFFFFFF0u : (uint32_t)dense;
+        p = (p + 7u) / 8u * 8u;
+        if (p > cap) p = cap;
+        d->scale[l] = sc; d->resolution[l] = res; d->offsets[l] = off;
+        off += p;
+    }
+    d->offsets[n_levels] = off;
+    return (int64_t)off * n_features;
+}
+
+static inline uint32_t grid_row(const grid_desc* d, int l, uint32_t x, uint32_t y, uint32_t z)
+{
+    const uint32_t size = d->offsets[l + 1] - d->offsets[l], res = d->resolution[l];
+    uint32_t stride = 1, idx = 0;
+    const uint32_t p[3] = { x, y, z };
+    for (int k = 0; k < 3 && stride <= size; k++) { idx += p[k] * stride; stride *= res; }
+    if (size < stride) idx = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
+    return d->offsets[l] + idx % size;
+}
+
+int ngp_cpu_grid_fwd(const grid_desc* d, const float* table, const float* x, int64_t n, float* y)
+{
+    const int L = (int)d->n_levels, F = (int)d->n_features;
+    #pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        for (int l = 0; l < L; l++) {
+            float w[3]; uint32_t g[3];
+            for (int k = 0; k < 3; k++) {
+                const float p = fmaf(d->scale[l], x[3 * i + k], 0.5f);
+                const float fl = floorf(p);
+                g[k] = (uint32_t)(int)fl; w[k] = p - fl;
+            }
+            float* out = y + ((size_t)i * L + l) * F;
+            for (int f = 0; f < F; f++) out[f] = 0;
+            for (int c = 0; c < 8; c++) {
+                float wt = 1; uint32_t q[3];
+                for (int k = 0; k < 3; k++) {
+                    if (c & (1 << k)) { wt *= w[k]; q[k] = g[k] + 1; } else { wt *= 1 - w[k]; q[k] = g[k]; }
+                }
+                const float* row = table + (size_t)grid_row(d, l, q[0], q[1], q[2]) * F;
+                for (int f = 0; f < F; f++) out[f] = fmaf(wt, row[f], out[f]);
+            }
+        }
+    }
+    return 0;
+}
+
+/* dtable must be zero (or hold a running sum) on entry; sequential accumulation */
+int ngp_cpu_grid_bwd_param(const grid_desc* d, const float* x, const float* dL_dy, int64_t n, float* dtable)
+{
+    const int L = (int)d->n_levels, F = (int)d->n_features;
+    for (int64_t i = 0; i < n; i++)
+        for (int l = 0; l < L; l++) {
+            float w[3]; uint32_t g[3];
+            for (int k = 0; k < 3; k++) {
+                const float p = fmaf(d->scale[l], x[3 * i + k], 0.5f);
+                const float fl = floorf(p);
+                g[k] = (uint32_t)(int)fl; w[k] = p - fl;
+            }
+            const float* go = dL_dy + ((size_t)i * L + l) * F;
+            for (int c = 0; c < 8; c++) {
+                float wt = 1; uint32_t q[3];
+                for (int k = 0; k < 3; k++) {
+                    if (c & (1 << k)) { wt *= w[k]; q[k] = g[k] + 1; } else { wt *= 1 - w[k]; q[k] = g[k]; }
+                }
+                float* row = dtable + (size_t)grid_row(d, l, q[0], q[1], q[2]) * F;
+                for (int f = 0; f < F; f++) row[f] += wt * go[f];
+            }
+        }
+    return 0;
+}
+
+int ngp_cpu_grid_bwd_input(const grid_desc* d, const float* table, const float* x, const float* dL_dy,
+                           int64_t n, float* dL_dx)
+{
+    const int L = (int)d->n_levels, F = (int)d->n_features;
+    #pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        float acc[3] = { 0, 0, 0 };
+        for (int l = 0; l < L; l++) {
+            float w[3]; uint32_t g[3];
+            for (int k = 0; k < 3; k++) {
+                const float p = fmaf(d->scale[l], x[3 * i + k], 0.5f);
+                const float fl = floorf(p);
+                g[k] = (uint32_t)(int)fl; w[k] = p - fl;
+            }
+            const float* go = dL_dy + ((size_t)i * L + l) * F;
+            for (int gd = 0; gd < 3; gd++) {
+                const int a = (gd + 1) % 3, b = (gd + 2) % 3;
+                for (int c = 0; c < 4; c++) {
+                    uint32_t q0[3], q1[3]; float wt = d->scale[l];
+                    const int ca = c & 1, cb = (c >> 1) & 1;
+                    wt *= ca ? w[a] : 1 - w[a];
+                    wt *= cb ? w[b] : 1 - w[b];
+                    q0[a] = q1[a] = g[a] + (uint32_t)ca; q0[b] = q1[b] = g[b] + (uint32_t)cb;
+                    q0[gd] = g[gd]; q1[gd] = g[gd] + 1;
+                    const float* r0 = table + (size_t)grid_row(d, l, q0[0], q0[1], q0[2]) * F;
+                    const float* r1 = table + (size_t)grid_row(d, l, q1[0], q1[1], q1[2]) * F;
+                    float dot = 0;
+                    for (int f = 0; f < F; f++) dot += go[f] * (r1[f] - r0[f]);
+                    acc[gd] += wt * dot;
+                }
+            }
+        }
+        dL_dx[3 * i] = acc[0]; dL_dx[3 * i + 1] = acc[1]; dL_dx[3 * i + 2] = acc[2];
+    }
+    return 0;
+}
+
+/* Double backward of grid_bwd_input: dL_dx = J(x,table)^T dL_dy is bilinear in (table, dL_dy);
+ * given v = dLoss/d(dL_dx) (n,3): dtable += d/dtable <v, dL_dx>, dL_ddLdy = d/d(dL_dy) <v, dL_dx>.
+ * (Second-order dependence on x through the weights is not propagated, as in tcnn.) */
+int ngp_cpu_grid_bwd_bwd_input(const grid_desc* d, const float* table, const float* x, const float* dL_dy,
+                               const float* v, int64_t n, float* dtable, float* dL_ddLdy)
+{
+    const int L = (int)d->n_levels, F = (int)d->n_features;
+    for (int64_t i = 0; i < n; i++)
+        for (int l = 0; l < L; l++) {
+            float w[3]; uint32_t g[3];
+            for (int k = 0; k < 3; k++) {
+                const float p = fmaf(d->scale[l], x[3 * i + k], 0.5f);
+                const float fl = floorf(p);
+                g[k] = (uint32_t)(int)fl; w[k] = p - fl;
+            }
+            const float* go = dL_dy + ((size_t)i * L + l) * F;
+            float* ddy = dL_ddLdy ? dL_ddLdy + ((size_t)i * L + l) * F : 0;
+            if (ddy) for (int f = 0; f < F; f++) ddy[f] = 0;
+            for (int gd = 0; gd < 3; gd++) {
+                const int a = (gd + 1) % 3, b = (gd + 2) % 3;
+                for (int c = 0; c < 4; c++) {
+                    uint32_t q0[3], q1[3]; float wt = d->scale[l] * v[3 * i + gd];
+                    const int ca = c & 1, cb = (c >> 1) & 1;
+                    wt *= ca ? w[a] : 1 - w[a];
+                    wt *= cb ? w[b] : 1 - w[b];
+                    q0[a] = q1[a] = g[a] + (uint32_t)ca; q0[b] = q1[b] = g[b] + (uint32_t)cb;
+                    q0[gd] = g[gd]; q1[gd] = g[gd] + 1;
+                    const size_t i0 = (size_t)grid_row(d, l, q0[0], q0[1], q0[2]) * F;
+                    const size_t i1 = (size_t)grid_row(d, l, q1[0], q1[1], q1[2]) * F;
+                    for (int f = 0; f < F; f++) {
+                        if (dtable) { dtable[i1 + f] += wt * go[f]; dtable[i0 + f] -= wt * go[f]; }
+                        if (ddy) ddy[f] += wt * (table[i1 + f] - table[i0 + f]);
+                    }
+                }
+            }
+        }
+    return 0;
+}
+
+/* SphericalHarmonics degree<=4: input in [0,1] mapped to [-1,1] (Appendix B) */
+static void sh_eval(float x, float y, float z, int degree, float* o)
+{
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    o[0] = 0.28209479177387814f;
+    if (degree <= 1) return;
+    o[1] = -0.48860251190291987f * y; o[2] = 0.48860251190291987f * z; o[3] = -0.48860251190291987f * x;
+    if (degree <= 2) return;
+    o[4] = 1.0925484305920792f * xy; o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz; o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    if (degree <= 3) return;
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+int ngp_cpu_sh_fwd(const float* x, int64_t n, int degree, float* y)
+{
+    const int D = degree * degree;
+    #pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++)
+        sh_eval(x[3 * i] * 2 - 1, x[3 * i + 1] * 2 - 1, x[3 * i + 2] * 2 - 1, degree, y + (size_t)i * D);
+    return 0;
+}
+
+/* y (n,n_out) = act(x . W^T + b); act codes as include/ngp_hip.h */
+static inline float act_apply(float v, int act)
+{
+    switch (act) {
+        case 1: return v > 0 ? v : 0;
+        case 2: return 1.0f / (1.0f + expf(-v));
+        case 3: return v > 20.0f ? v : log1pf(expf(v));
+        case 4: return expf(v);
+        default: return v;
+    }
+}
+
+int ngp_cpu_linear_fwd(const float* x, int64_t ldx, const float* W, const float* b, int64_t n,
+                       int n_in, int n_out, int act, float* y, int64_t ldy)
+{
+    #pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++)
+        for (int o = 0; o < n_out; o++) {
+            float a = b ? b[o] : 0.0f;
+            const float* xr = x + (size_t)i * ldx; const float* wr = W + (size_t)o * n_in;
+            for (int k = 0; k < n_in; k++) a += xr[k] * wr[k];
+            y[(size_t)i * ldy + o] = act_apply(a, act);
+        }
+    return 0;
+}
+
+int ngp_cpu_num_threads(void)
+{
+#ifdef _OPENMP
+    extern int omp_get_max_threads(void);
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE'S OWN pure-torch functions.
+
+Runs only in the build container (needs /root/reference); the GPU box uses the committed
+.npz files.  The reference's `models.custom_functions` / `models.rendering_noCUDA` import
+`vren` and `torch_scatter` (absent here: CUDA extension / un-vendored dependency) and call
+`.cuda()`; they are imported with empty stand-in modules for those two names and an identity
+`Tensor.cuda`, which leaves every function exercised here (pure torch) untouched.
+`RayAABBIntersector` (a vren call) is replaced by a pure-torch slab test for the
+rendering_noCUDA.render case; its outputs are stored in the fixture as inputs.
+
+Fixtures hold numbers only (inputs and the reference's outputs).  Seed 20220806 = the
+reference's own seed (train.py:402).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+SEED = 20220806
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    for name in ("vren", "torch_scatter"):
+        sys.modules[name] = types.ModuleType(name)
+
+    def segment_csr(src, indptr):
+        return torch.stack([src[indptr[i]:indptr[i + 1]].sum(0) for i in range(len(indptr) - 1)])
+
+    sys.modules["torch_scatter"].segment_csr = segment_csr
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from models import custom_functions as cf
+    from models import rendering_noCUDA as rn
+    return cf, rn
+
+
+def npz(name, **arrs):
+    np.savez_compressed(os.path.join(OUT, name), **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                                   for k, v in arrs.items()})
+    print("wrote", name, {k: tuple(np.shape(v)) for k, v in arrs.items()})
+
+
+def g1_raw2outputs(cf):
+    torch.manual_seed(SEED)
+    cases = {}
+    idx = 0
+    for (R, S) in [(1, 1), (4, 1), (4, 8), (257, 8), (4, 64), (2, 1024)]:
+        for C in (0, 7, 10):
+            for kind in ("zero", "uniform", "huge"):
+                if kind != "uniform" and (R, S) not in [(4, 8), (2, 1024)]:
+                    continue
+                raw = torch.rand(R, S, 10 + C)
+                if kind == "zero":
+                    raw[..., 0] = 0
+                elif kind == "uniform":
+                    raw[..., 0] = raw[..., 0] * 50
+                else:
+                    raw[..., 0] = raw[..., 0] * 1e6
+                z = torch.sort(torch.rand(R, S) * 3 + 0.05, -1)[0]
+                d = torch.randn(R, 3)
+                outs = cf.raw2outputs(raw, z, d, classes=C)
+                p = f"c{idx}_"
+                cases[p + "raw"], cases[p + "z"], cases[p + "d"] = raw, z, d
+                cases[p + "classes"] = np.int64(C)
+                for n, o in zip(("opacity", "rgb", "normal_raw", "normal_pred", "sem", "ws", "depth"), outs):
+                    cases[p + n] = o
+                idx += 1
+    cases["n_cases"] = np.int64(idx)
+    npz("g1_raw2outputs.npz", **cases)
+
+
+def g2_sample_pdf(cf):
+    torch.manual_seed(SEED + 1)
+    cases = {}
+    idx = 0
+    for (R, nb, ns) in [(1, 8, 16), (5, 63, 64), (3, 63, 128), (4, 30, 7)]:
+        bins = torch.sort(torch.rand(R, nb + 1) * 4, -1)[0]
+        w = torch.rand(R, nb)
+        w[0] = 0  # a zero-weight row
+        if R > 2:
+            w[2, : nb // 2] = 0
+        out = cf.sample_pdf(bins, w, ns, det=True)
+        p = f"c{idx}_"
+        cases[p + "bins"], cases[p + "w"], cases[p + "n"], cases[p + "out"] = bins, w, np.int64(ns), out
+        idx += 1
+    cases["n_cases"] = np.int64(idx)
+    npz("g2_sample_pdf.npz", **cases)
+
+
+class FakeField(torch.nn.Module):
+    """Analytic field; tests/test_oracle_golden.py carries the same formulas in numpy."""
+
+    def __init__(self, classes, last):
+        super().__init__()
+        self.classes, self.last = classes, last
+        self.register_buffer("center", torch.zeros(1, 3))
+        self.register_buffer("half_size", torch.ones(1, 3) * 0.5)
+        self.register_buffer("M", torch.linspace(-1, 1, 3 * classes).reshape(3, classes))
+
+    def forward(self, x, d, embed_a, **kw):
+        r2 = (x * x).sum(-1)
+        sig = 40 * torch.exp(-r2 / 0.05)
+        rgb = 0.5 + 0.5 * torch.sin(8 * x) * (0.5 + 0.5 * embed_a[:, :1])
+        sems = torch.softmax(x @ self.M, -1)
+        if not self.last:
+            return sig, rgb, sems
+        n_raw = -x / torch.sqrt(r2 + 1e-6)[:, None]
+        n_pred = 0.5 * n_raw + 0.1
+        return sig, rgb, n_raw, n_pred, sems, None
+
+
+def torch_aabb(rays_o, rays_d, center, half_size):
+    inv = 1.0 / rays_d
+    a = (center - half_size - rays_o) * inv
+    b = (center + half_size - rays_o) * inv
+    t1 = torch.minimum(a, b).max(-1)[0]
+    t2 = torch.maximum(a, b).min(-1)[0]
+    miss = t1 > t2
+    t1 = torch.where(miss, -torch.ones_like(t1), t1)
+    t2 = torch.where(miss, -torch.ones_like(t2), t2)
+    hit = t2 > 0
+    out = -torch.ones(len(rays_o), 1, 2)
+    out[hit, 0, 0] = t1[hit].clamp(min=0)
+    out[hit, 0, 1] = t2[hit]
+    return hit.int(), out, torch.where(hit, 0, -1)[:, None]
+
+
+def g3_render(cf, rn):
+    C = 7
+    torch.manual_seed(SEED + 2)
+    n = 96
+    # cameras on a sphere of radius 1.5 looking roughly at the origin (all rays hit the box)
+    o = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1) * 1.5
+    tgt = (torch.rand(n, 3) - 0.5) * 0.6
+    d = torch.nn.functional.normalize(tgt - o, dim=-1) * (1.0 + 0.2 * torch.rand(n, 1))
+
+    class Intersector:
+        @staticmethod
+        def apply(rays_o, rays_d, center, half_size, max_hits):
+            return torch_aabb(rays_o, rays_d, center, half_size)
+
+    rn.RayAABBIntersector = Intersector
+    cases = {"rays_o": o, "rays_d": d, "classes": np.int64(C)}
+    for tag, samples in (("a", [64]), ("b", [32, 64])):
+        emb = [torch.rand(n, 4) for _ in samples]
+        kwargs = {"samples": samples, "num_classes": C, "test_time": False}
+        for i, e in enumerate(emb):
+            kwargs[f"embedding_a{i}"] = e
+        models = [FakeField(C, last=False), FakeField(C, last=True)]
+        torch.manual_seed(SEED + 3)
+        u = torch.rand(n)
+        torch.manual_seed(SEED + 3)
+        res = rn.render(models, o, d, **kwargs)
+        cases[tag + "_samples"] = np.asarray(samples, np.int64)
+        cases[tag + "_t_rand_u"] = u
+        for i, e in enumerate(emb):
+            cases[f"{tag}_emb{i}"] = e
+        for k, v in res.items():
+            if torch.is_tensor(v):
+                cases[f"{tag}_{k}"] = v
+    npz("g3_render_nocuda.npz", **cases)
+
+
+def g4_activations(cf):
+    torch.manual_seed(SEED + 4)
+    x = torch.cat([torch.randn(200) * 3, torch.tensor([-20.0, -7.0, 0.0, 7.0, 15.0, 20.0])])
+    g = torch.randn_like(x)
+    cases = {"x": x, "g": g}
+    for name, fn in (("trunc_exp", cf.TruncExp), ("relu", cf.ReLU), ("trunc_tanh", cf.TruncTanh)):
+        xi = x.clone().requires_grad_(True)
+        y = fn.apply(xi)
+        y.backward(g)
+        cases[name + "_y"], cases[name + "_dx"] = y.detach(), xi.grad
+    npz("g4_activations.npz", **cases)
+
+
+def g5_raymarcher_bw(cf):
+    torch.manual_seed(SEED + 5)
+    counts = torch.tensor([3, 0, 5, 1, 0, 7, 2])
+    starts = torch.cumsum(counts, 0) - counts
+    rays_a = torch.stack([torch.arange(len(counts)), starts, counts], 1).long()
+    N = int(counts.sum())
+    ts = torch.rand(N)
+    dxyz, ddirs = torch.randn(N, 3), torch.randn(N, 3)
+
+    class Ctx:
+        saved_tensors = (rays_a, ts)
+
+    out = cf.RayMarcher.backward(Ctx, None, dxyz, ddirs, None, None, None)
+    npz("g5_raymarcher_bw.npz", rays_a=rays_a, ts=ts, dL_dxyzs=dxyz, dL_ddirs=ddirs,
+        dL_drays_o=out[0], dL_drays_d=out[1])
+
+
+if __name__ == "__main__":
+    cf, rn = import_reference()
+    g1_raw2outputs(cf)
+    g2_sample_pdf(cf)
+    g3_render(cf, rn)
+    g4_activations(cf)
+    g5_raymarcher_bw(cf)
