@@ -259,19 +259,21 @@ int ngp_sh_bwd_input(const float* x, const float* dL_dy, int64_t n, int degree,
  *                        (atomic split-K over samples; caller zeroes dW/db)
  * ngp_act_bwd : dz = dy * act'(.)  given the layer OUTPUT y (post-activation)
  *               for ReLU/Sigmoid/Exp, or the pre-activation for Softplus.
- * ldx/ldy/lddz/lddx are row strides in floats (>= the logical width).
+ * ldx/ldy/lddz/lddx/ldw are row strides in floats (>= the logical width); a W sub-block
+ * (e.g. the columns of rgb_net's first layer that see the grid features) is addressed by
+ * offsetting W and keeping ldw.
  * ---------------------------------------------------------------------- */
-int ngp_linear_fwd(const float* x, int64_t ldx, const float* W, const float* b,
+int ngp_linear_fwd(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* b,
                    int64_t n, int n_in, int n_out, int activation,
                    float* y, int64_t ldy, float* z_pre /* optional (n,n_out) pre-activation, may be NULL */,
                    void* stream);
 
-int ngp_linear_bwd_input(const float* dz, int64_t lddz, const float* W,
+int ngp_linear_bwd_input(const float* dz, int64_t lddz, const float* W, int64_t ldw,
                          int64_t n, int n_in, int n_out, float* dx, int64_t lddx, void* stream);
 
 int ngp_linear_bwd_weight(const float* dz, int64_t lddz, const float* x, int64_t ldx,
-                          int64_t n, int n_in, int n_out, float* dW, float* db /* may be NULL */,
-                          void* stream);
+                          int64_t n, int n_in, int n_out, float* dW, int64_t ldw,
+                          float* db /* may be NULL */, void* stream);
 
 int ngp_act_bwd(const float* dy, const float* y_or_z, int64_t count, int activation,
                 float* dz, void* stream);
@@ -289,6 +291,11 @@ int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
 
 /* sum of squares of a flat tensor accumulated into *out (device scalar; caller zeroes) */
 int ngp_sumsq(const float* x, int64_t n, float* out, void* stream);
+
+/* torch.nn.utils.clip_grad_norm_ coefficient (train.py: gradient_clip_val=50) on device:
+ * norm = sqrt(*sumsq)*extra_scale; *coef = extra_scale * min(1, max_norm/(norm+1e-6)).
+ * extra_scale carries 1/world_size for summed (not yet averaged) data-parallel gradients. */
+int ngp_clip_coef(const float* sumsq, float max_norm, float extra_scale, float* coef, void* stream);
 
 #ifdef __cplusplus
 }

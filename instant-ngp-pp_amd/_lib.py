@@ -1,0 +1,105 @@
+"""ctypes binding of libngp_hip.so (the C ABI in include/ngp_hip.h).
+
+The prototypes are parsed from the header at import time, so the Python side cannot drift
+from the declared ABI.  There is NO CPU fallback: if the library is missing and cannot be
+built, or a call returns an error code, this module raises.
+"""
+import ctypes as C
+import os
+import re
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(HERE, "..", "include", "ngp_hip.h")
+LIB_PATH = os.path.join(HERE, "libngp_hip.so")
+
+_CTYPES = {
+    "int": C.c_int, "int64_t": C.c_int64, "float": C.c_float, "double": C.c_double,
+    "uint32_t": C.c_uint32,
+}
+
+
+class GridDesc(C.Structure):
+    """struct ngp_grid_desc"""
+    _fields_ = [("n_levels", C.c_uint32), ("n_features", C.c_uint32),
+                ("offsets", C.c_uint32 * 33), ("resolution", C.c_uint32 * 32), ("scale", C.c_float * 32)]
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [(ctype, argname), ...])} for every `ngp_*` prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    protos = {}
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(ngp_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        restype = {"int": C.c_int, "int64_t": C.c_int64, "const char*": C.c_char_p}[ret]
+        argl = []
+        args = args.strip()
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                an = re.search(r"(\w+)$", a).group(1)
+                ty = a[: a.rfind(an)].strip()
+                if "*" in ty:
+                    argl.append((C.c_void_p, an))
+                else:
+                    argl.append((_CTYPES[ty.replace("const ", "").strip()], an))
+        protos[name] = (restype, argl)
+    return protos
+
+
+PROTOS = parse_header()
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build  # builds with hipcc; raises if hipcc is absent
+        _build.build()
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argl) in PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = [t for t, _ in argl]
+    _lib = lib
+    return lib
+
+
+def check_input(t, name="x"):
+    """CHECK_INPUT of the reference (models/csrc/include/utils.h:4-6)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _arg(v):
+    if v is None:
+        return None
+    if isinstance(v, torch.Tensor):
+        return v.data_ptr()
+    if isinstance(v, C.Structure):
+        return C.addressof(v)
+    return v
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Calls ngp_<name>(*args, current HIP stream).  Tensors are passed as device pointers."""
+    lib = load()
+    rc = getattr(lib, "ngp_" + name)(*[_arg(a) for a in args], stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f"ngp_{name} failed with code {rc}")
+
+
+def call_host(name, *args):
+    """Host-only entry points (no stream argument); returns the raw result."""
+    return getattr(load(), "ngp_" + name)(*[_arg(a) for a in args])

@@ -1,0 +1,591 @@
+// Ray-segment kernels: alpha compositing (train fw/bw, alpha-only, test), Ref-NeRF normal
+// regularisers, distortion loss, segment_csr.
+//
+// Layout: one 32-lane half-wave per rays_a row.  The lanes of a half-wave take 32
+// consecutive samples of the ray (coalesced loads), the transmittance T_k = prod(1-a_j) is a
+// multiplicative scan across the lanes, early termination is a ballot on T <= T_threshold,
+// and per-ray outputs are one cross-lane reduction at the end.  The reference walks each ray
+// serially in one thread (volumerendering.cu:84-114 etc.).
+//
+// Differences from the serial walk are confined to fp32 summation/product association.
+#include "common.h"
+
+namespace {
+
+struct Seg {
+    int64_t ray, start;
+    int n;
+};
+
+__device__ __forceinline__ bool seg_load(const int64_t* __restrict__ rays_a, int n_rays, Seg& s, int& lane32)
+{
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = gtid >> 5;
+    lane32 = threadIdx.x & 31;
+    if (row >= n_rays) return false;
+    s.ray = rays_a[3 * (size_t)row];
+    s.start = rays_a[3 * (size_t)row + 1];
+    s.n = (int)rays_a[3 * (size_t)row + 2];
+    return true;
+}
+
+// Per-chunk transmittance bookkeeping shared by all compositing kernels.
+struct Chunk {
+    float a, T_before, T_after;
+    bool valid, active;
+    int first; // lane of the stopping sample inside this chunk, or -1
+};
+
+__device__ __forceinline__ Chunk chunk_alpha(const float* __restrict__ sigmas, const float* __restrict__ deltas,
+                                             int64_t s, bool valid, float T_run, float T_thr, int lane32)
+{
+    Chunk c;
+    c.valid = valid;
+    const float sig = valid ? sigmas[s] : 0.0f;
+    const float dl = valid ? deltas[s] : 0.0f;
+    c.a = valid ? 1.0f - __expf(-sig * dl) : 0.0f;
+    const float om = 1.0f - c.a;
+    const float pin = half_incl_scan_mul(om, lane32);
+    float pex = __shfl_up(pin, 1, 32);
+    if (lane32 == 0) pex = 1.0f;
+    c.T_before = T_run * pex;
+    c.T_after = T_run * pin;
+    const bool stopped = valid && (c.T_after <= T_thr);
+    c.first = half_first(__ballot(stopped), threadIdx.x & 63);
+    c.active = valid && (c.first < 0 || lane32 <= c.first);
+    return c;
+}
+
+// ------------------------------------------------------------------ composite_alpha_fw
+__global__ void composite_alpha_fw_kernel(const float* __restrict__ sigmas, const float* __restrict__ deltas,
+                                          const int64_t* __restrict__ rays_a, float T_thr, int n_rays,
+                                          float* __restrict__ alphas, float* __restrict__ ws)
+{
+    Seg sg; int lane;
+    if (!seg_load(rays_a, n_rays, sg, lane)) return;
+    float T_run = 1.0f;
+    int k0 = 0;
+    for (; k0 < sg.n; k0 += 32) {
+        const int k = k0 + lane;
+        const int64_t s = sg.start + k;
+        const Chunk c = chunk_alpha(sigmas, deltas, s, k < sg.n, T_run, T_thr, lane);
+        if (c.valid) { alphas[s] = c.active ? c.a : 0.0f; ws[s] = c.active ? c.a * c.T_before : 0.0f; }
+        if (c.first >= 0) { k0 += 32; break; }
+        T_run = __shfl(c.T_after, 31, 32);
+    }
+    for (; k0 < sg.n; k0 += 32) {
+        const int k = k0 + lane;
+        if (k < sg.n) { alphas[sg.start + k] = 0.0f; ws[sg.start + k] = 0.0f; }
+    }
+}
+
+// ------------------------------------------------------------------ composite_train_fw (V1)
+template <int CMAX>
+__global__ void composite_train_fw_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                          const float* __restrict__ normals, const float* __restrict__ sems,
+                                          const float* __restrict__ deltas, const float* __restrict__ ts,
+                                          const int64_t* __restrict__ rays_a, float T_thr, int classes, int n_rays,
+                                          int64_t* __restrict__ total_samples, float* __restrict__ opacity,
+                                          float* __restrict__ depth, float* __restrict__ rgb,
+                                          float* __restrict__ normal, float* __restrict__ sem, float* __restrict__ ws)
+{
+    Seg sg; int lane;
+    if (!seg_load(rays_a, n_rays, sg, lane)) return;
+    float T_run = 1.0f;
+    float aO = 0, aD = 0, aR = 0, aG = 0, aB = 0, aNx = 0, aNy = 0, aNz = 0;
+    float aS[CMAX > 0 ? CMAX : 1];
+#pragma unroll
+    for (int c = 0; c < CMAX; c++) aS[c] = 0;
+    int stop = -1;
+    int k0 = 0;
+    for (; k0 < sg.n; k0 += 32) {
+        const int k = k0 + lane;
+        const int64_t s = sg.start + k;
+        const Chunk c = chunk_alpha(sigmas, deltas, s, k < sg.n, T_run, T_thr, lane);
+        const float w = c.active ? c.a * c.T_before : 0.0f;
+        if (c.valid) {
+            ws[s] = w;
+            aO += w;
+            aD += w * ts[s];
+            aR += w * rgbs[3 * s]; aG += w * rgbs[3 * s + 1]; aB += w * rgbs[3 * s + 2];
+            aNx += w * normals[3 * s]; aNy += w * normals[3 * s + 1]; aNz += w * normals[3 * s + 2];
+#pragma unroll
+            for (int cc = 0; cc < CMAX; cc++)
+                if (cc < classes) aS[cc] += w * sems[s * classes + cc];
+        }
+        if (c.first >= 0) { stop = k0 + c.first; k0 += 32; break; }
+        T_run = __shfl(c.T_after, 31, 32);
+    }
+    for (; k0 < sg.n; k0 += 32) { // samples behind the stop: zero weight
+        const int k = k0 + lane;
+        if (k < sg.n) ws[sg.start + k] = 0.0f;
+    }
+    aO = half_sum(aO); aD = half_sum(aD);
+    aR = half_sum(aR); aG = half_sum(aG); aB = half_sum(aB);
+    aNx = half_sum(aNx); aNy = half_sum(aNy); aNz = half_sum(aNz);
+#pragma unroll
+    for (int cc = 0; cc < CMAX; cc++)
+        if (cc < classes) aS[cc] = half_sum(aS[cc]);
+    if (lane == 0) {
+        const size_t r = (size_t)sg.ray;
+        total_samples[r] = stop >= 0 ? stop : sg.n;
+        opacity[r] = aO; depth[r] = aD;
+        rgb[3 * r] = aR; rgb[3 * r + 1] = aG; rgb[3 * r + 2] = aB;
+        normal[3 * r] = aNx; normal[3 * r + 1] = aNy; normal[3 * r + 2] = aNz;
+#pragma unroll
+        for (int cc = 0; cc < CMAX; cc++)
+            if (cc < classes) sem[r * classes + cc] = aS[cc];
+    }
+}
+
+// ------------------------------------------------------------------ composite_train_bw (V2)
+template <int CMAX>
+__global__ void composite_train_bw_kernel(const float* __restrict__ dL_dopacity, const float* __restrict__ dL_ddepth,
+                                          const float* __restrict__ dL_drgb, const float* __restrict__ dL_dnormal,
+                                          const float* __restrict__ dL_dsem, const float* __restrict__ dL_dws,
+                                          const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                          const float* __restrict__ ws, const float* __restrict__ deltas,
+                                          const float* __restrict__ ts, const int64_t* __restrict__ rays_a,
+                                          const float* __restrict__ opacity, const float* __restrict__ depth,
+                                          const float* __restrict__ rgb, float T_thr, int classes, int n_rays,
+                                          float* __restrict__ dL_dsigmas, float* __restrict__ dL_drgbs,
+                                          float* __restrict__ dL_dnormals, float* __restrict__ dL_dsems)
+{
+    Seg sg; int lane;
+    if (!seg_load(rays_a, n_rays, sg, lane)) return;
+    if (sg.n <= 0) return;
+    const size_t r = (size_t)sg.ray;
+    const float R = rgb[3 * r], G = rgb[3 * r + 1], B = rgb[3 * r + 2];
+    const float O = opacity[r], D = depth[r];
+    const float gR = dL_drgb[3 * r], gG = dL_drgb[3 * r + 1], gB = dL_drgb[3 * r + 2];
+    const float gO = dL_dopacity[r], gD = dL_ddepth[r];
+    const float gNx = dL_dnormal[3 * r], gNy = dL_dnormal[3 * r + 1], gNz = dL_dnormal[3 * r + 2];
+    float gS[CMAX > 0 ? CMAX : 1];
+#pragma unroll
+    for (int cc = 0; cc < CMAX; cc++) gS[cc] = cc < classes ? dL_dsem[r * classes + cc] : 0.0f;
+
+    // total of dL_dws*ws over the whole segment (volumerendering.cu:206-210)
+    float tot = 0.0f;
+    for (int k = lane; k < sg.n; k += 32) tot += dL_dws[sg.start + k] * ws[sg.start + k];
+    tot = half_sum(tot);
+
+    float T_run = 1.0f, r_run = 0, g_run = 0, b_run = 0, d_run = 0, p_run = 0;
+    int k0 = 0;
+    for (; k0 < sg.n; k0 += 32) {
+        const int k = k0 + lane;
+        const int64_t s = sg.start + k;
+        const Chunk c = chunk_alpha(sigmas, deltas, s, k < sg.n, T_run, T_thr, lane);
+        const float w = c.valid ? c.a * c.T_before : 0.0f;
+        float cr = 0, cg = 0, cb = 0, tt = 0, dws = 0, dl = 0, wsv = 0;
+        if (c.valid) {
+            cr = rgbs[3 * s]; cg = rgbs[3 * s + 1]; cb = rgbs[3 * s + 2];
+            tt = ts[s]; dws = dL_dws[s]; dl = deltas[s]; wsv = ws[s];
+        }
+        const float ri = r_run + half_incl_scan_add(w * cr, lane);
+        const float gi = g_run + half_incl_scan_add(w * cg, lane);
+        const float bi = b_run + half_incl_scan_add(w * cb, lane);
+        const float di = d_run + half_incl_scan_add(w * tt, lane);
+        const float pi = p_run + half_incl_scan_add(dws * wsv, lane);
+        if (c.valid) {
+            const float wa = c.active ? w : 0.0f;
+            dL_drgbs[3 * s] = gR * wa; dL_drgbs[3 * s + 1] = gG * wa; dL_drgbs[3 * s + 2] = gB * wa;
+            dL_dnormals[3 * s] = gNx * wa; dL_dnormals[3 * s + 1] = gNy * wa; dL_dnormals[3 * s + 2] = gNz * wa;
+#pragma unroll
+            for (int cc = 0; cc < CMAX; cc++)
+                if (cc < classes) dL_dsems[s * classes + cc] = gS[cc] * wa;
+            const float T = c.T_after;
+            const float v = dl * (gR * (cr * T - (R - ri)) +
+                                  gG * (cg * T - (G - gi)) +
+                                  gB * (cb * T - (B - bi)) +
+                                  gO * (1 - O) +
+                                  gD * (tt * T - (D - di)) +
+                                  T * dws - (tot - pi));
+            dL_dsigmas[s] = c.active ? v : 0.0f;
+        }
+        if (c.first >= 0) { k0 += 32; break; }
+        T_run = __shfl(c.T_after, 31, 32);
+        r_run = __shfl(ri, 31, 32); g_run = __shfl(gi, 31, 32); b_run = __shfl(bi, 31, 32);
+        d_run = __shfl(di, 31, 32); p_run = __shfl(pi, 31, 32);
+    }
+    for (; k0 < sg.n; k0 += 32) {
+        const int k = k0 + lane;
+        if (k < sg.n) {
+            const int64_t s = sg.start + k;
+            dL_dsigmas[s] = 0.0f;
+            dL_drgbs[3 * s] = 0.0f; dL_drgbs[3 * s + 1] = 0.0f; dL_drgbs[3 * s + 2] = 0.0f;
+            dL_dnormals[3 * s] = 0.0f; dL_dnormals[3 * s + 1] = 0.0f; dL_dnormals[3 * s + 2] = 0.0f;
+            for (int cc = 0; cc < classes; cc++) dL_dsems[s * classes + cc] = 0.0f;
+        }
+    }
+}
+
+// Generic-classes fallbacks (classes > 32): semantic channels handled by a second sweep that
+// re-derives w from the ws written by the first sweep.
+__global__ void composite_sem_fw_kernel(const float* __restrict__ ws, const float* __restrict__ sems,
+                                        const int64_t* __restrict__ rays_a, int classes, int n_rays,
+                                        float* __restrict__ sem)
+{
+    Seg sg; int lane;
+    if (!seg_load(rays_a, n_rays, sg, lane)) return;
+    for (int cc = 0; cc < classes; cc++) {
+        float a = 0.0f;
+        for (int k = lane; k < sg.n; k += 32) a += ws[sg.start + k] * sems[(sg.start + k) * classes + cc];
+        a = half_sum(a);
+        if (lane == 0) sem[(size_t)sg.ray * classes + cc] = a;
+    }
+}
+
+__global__ void composite_sem_bw_kernel(const float* __restrict__ dL_dsem, const float* __restrict__ w_eff,
+                                        const int64_t* __restrict__ rays_a, int classes, int n_rays,
+                                        float* __restrict__ dL_dsems)
+{
+    Seg sg; int lane;
+    if (!seg_load(rays_a, n_rays, sg, lane)) return;
+    for (int k = lane; k < sg.n; k += 32) {
+        const int64_t s = sg.start + k;
+        const float w = w_eff[s];
+        for (int cc = 0; cc < classes; cc++) dL_dsems[s * classes + cc] = dL_dsem[(size_t)sg.ray * classes + cc] * w;
+    }
+}
+
+// ------------------------------------------------------------------ composite_test_fw (T1)
+// One lane per alive ray (<= 64 samples per call, volumerendering.cu:335-373).
+__global__ void composite_test_fw_kernel(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                         const float* __restrict__ normals, const float* __restrict__ normals_raw,
+                                         const float* __restrict__ sems, const float* __restrict__ deltas,
+                                         const float* __restrict__ ts, int64_t* __restrict__ alive, float T_thr,
+                                         int classes, const int32_t* __restrict__ n_eff, int n_alive, int n_samples,
+                                         float* __restrict__ opacity, float* __restrict__ depth,
+                                         float* __restrict__ rgb, float* __restrict__ normal,
+                                         float* __restrict__ normal_raw, float* __restrict__ sem)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int ne = n_eff[n];
+    if (ne == 0) { alive[n] = -1; return; }
+    const size_t r = (size_t)alive[n];
+    // accumulators start from the running per-ray values so that the additions happen in the
+    // reference's order (volumerendering.cu:352-365 adds sample by sample into the outputs)
+    float aO = opacity[r], aD = depth[r];
+    float T = 1 - aO;
+    float aR = rgb[3 * r], aG = rgb[3 * r + 1], aB = rgb[3 * r + 2];
+    float nx = normal[3 * r], ny = normal[3 * r + 1], nz = normal[3 * r + 2];
+    float rx = normal_raw[3 * r], ry = normal_raw[3 * r + 1], rz = normal_raw[3 * r + 2];
+    int s = 0;
+    bool dead = false;
+    while (s < ne) {
+        const size_t o = (size_t)n * n_samples + s;
+        const float a = 1.0f - __expf(-sigmas[o] * deltas[o]);
+        const float w = a * T;
+        aR += w * rgbs[3 * o]; aG += w * rgbs[3 * o + 1]; aB += w * rgbs[3 * o + 2];
+        aD += w * ts[o]; aO += w;
+        nx += w * normals[3 * o]; ny += w * normals[3 * o + 1]; nz += w * normals[3 * o + 2];
+        rx += w * normals_raw[3 * o]; ry += w * normals_raw[3 * o + 1]; rz += w * normals_raw[3 * o + 2];
+        for (int c = 0; c < classes; c++) sem[r * classes + c] += w * sems[o * classes + c];
+        T *= 1.0f - a;
+        if (T <= T_thr) { dead = true; break; }
+        s++;
+    }
+    rgb[3 * r] = aR; rgb[3 * r + 1] = aG; rgb[3 * r + 2] = aB;
+    depth[r] = aD; opacity[r] = aO;
+    normal[3 * r] = nx; normal[3 * r + 1] = ny; normal[3 * r + 2] = nz;
+    normal_raw[3 * r] = rx; normal_raw[3 * r + 1] = ry; normal_raw[3 * r + 2] = rz;
+    if (dead) alive[n] = -1;
+}
+
+// ------------------------------------------------------------------ RefLoss (V3)
+__global__ void refloss_fw_kernel(const float* __restrict__ sigmas, const float* __restrict__ ndiff,
+                                  const float* __restrict__ nori, const float* __restrict__ deltas,
+                                  const int64_t* __restrict__ rays_a, float T_thr, int n_rays,
+                                  float* __restrict__ loss_o, float* __restrict__ loss_p)
+{
+    Seg sg; int lane;
+    if (!seg_load(rays_a, n_rays, sg, lane)) return;
+    float T_run = 1.0f, ao = 0, ax = 0, ay = 0, az = 0;
+    for (int k0 = 0; k0 < sg.n; k0 += 32) {
+        const int k = k0 + lane;
+        const int64_t s = sg.start + k;
+        const Chunk c = chunk_alpha(sigmas, deltas, s, k < sg.n, T_run, T_thr, lane);
+        if (c.active) {
+            const float w = c.a * c.T_before;
+            ax += w * ndiff[3 * s]; ay += w * ndiff[3 * s + 1]; az += w * ndiff[3 * s + 2];
+            ao += w * nori[s];
+        }
+        if (c.first >= 0) break;
+        T_run = __shfl(c.T_after, 31, 32);
+    }
+    ao = half_sum(ao); ax = half_sum(ax); ay = half_sum(ay); az = half_sum(az);
+    if (lane == 0) {
+        const size_t r = (size_t)sg.ray;
+        loss_o[r] = ao; loss_p[3 * r] = ax; loss_p[3 * r + 1] = ay; loss_p[3 * r + 2] = az;
+    }
+}
+
+__global__ void refloss_bw_kernel(const float* __restrict__ dL_dlo, const float* __restrict__ dL_dlp,
+                                  const float* __restrict__ sigmas, const float* __restrict__ ndiff,
+                                  const float* __restrict__ nori, const float* __restrict__ deltas,
+                                  const int64_t* __restrict__ rays_a, const float* __restrict__ loss_o,
+                                  const float* __restrict__ loss_p, float T_thr, int n_rays,
+                                  float* __restrict__ dL_dsigmas, float* __restrict__ dL_dndiff,
+                                  float* __restrict__ dL_dnori)
+{
+    Seg sg; int lane;
+    if (!seg_load(rays_a, n_rays, sg, lane)) return;
+    const size_t r = (size_t)sg.ray;
+    const float X = loss_p[3 * r], Y = loss_p[3 * r + 1], Z = loss_p[3 * r + 2], O = loss_o[r];
+    const float gx = dL_dlp[3 * r], gy = dL_dlp[3 * r + 1], gz = dL_dlp[3 * r + 2], go = dL_dlo[r];
+    float T_run = 1.0f, x_run = 0, y_run = 0, z_run = 0, o_run = 0;
+    int k0 = 0;
+    for (; k0 < sg.n; k0 += 32) {
+        const int k = k0 + lane;
+        const int64_t s = sg.start + k;
+        const Chunk c = chunk_alpha(sigmas, deltas, s, k < sg.n, T_run, T_thr, lane);
+        const float w = c.valid ? c.a * c.T_before : 0.0f;
+        float dx = 0, dy = 0, dz = 0, no = 0, dl = 0;
+        if (c.valid) { dx = ndiff[3 * s]; dy = ndiff[3 * s + 1]; dz = ndiff[3 * s + 2]; no = nori[s]; dl = deltas[s]; }
+        const float xi = x_run + half_incl_scan_add(w * dx, lane);
+        const float yi = y_run + half_incl_scan_add(w * dy, lane);
+        const float zi = z_run + half_incl_scan_add(w * dz, lane);
+        const float oi = o_run + half_incl_scan_add(w * no, lane);
+        if (c.valid) {
+            const float wa = c.active ? w : 0.0f;
+            dL_dndiff[3 * s] = gx * wa; dL_dndiff[3 * s + 1] = gy * wa; dL_dndiff[3 * s + 2] = gz * wa;
+            dL_dnori[s] = go * wa;
+            const float T = c.T_after;
+            const float v = dl * (gx * (dx * T - (X - xi)) + gy * (dy * T - (Y - yi)) + gz * (dz * T - (Z - zi)) +
+                                  go * (no * T - (O - oi)));
+            dL_dsigmas[s] = c.active ? v : 0.0f;
+        }
+        if (c.first >= 0) { k0 += 32; break; }
+        T_run = __shfl(c.T_after, 31, 32);
+        x_run = __shfl(xi, 31, 32); y_run = __shfl(yi, 31, 32); z_run = __shfl(zi, 31, 32); o_run = __shfl(oi, 31, 32);
+    }
+    for (; k0 < sg.n; k0 += 32) {
+        const int k = k0 + lane;
+        if (k < sg.n) {
+            const int64_t s = sg.start + k;
+            dL_dsigmas[s] = 0.0f; dL_dnori[s] = 0.0f;
+            dL_dndiff[3 * s] = 0.0f; dL_dndiff[3 * s + 1] = 0.0f; dL_dndiff[3 * s + 2] = 0.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ distortion loss (D1)
+__global__ void distortion_fw_kernel(const float* __restrict__ ws, const float* __restrict__ deltas,
+                                     const float* __restrict__ ts, const int64_t* __restrict__ rays_a, int n_rays,
+                                     float* __restrict__ loss, float* __restrict__ ws_inc, float* __restrict__ wts_inc)
+{
+    Seg sg; int lane;
+    if (!seg_load(rays_a, n_rays, sg, lane)) return;
+    float w_run = 0, wt_run = 0, acc = 0;
+    for (int k0 = 0; k0 < sg.n; k0 += 32) {
+        const int k = k0 + lane;
+        const int64_t s = sg.start + k;
+        const bool valid = k < sg.n;
+        const float w = valid ? ws[s] : 0.0f;
+        const float wt = valid ? w * ts[s] : 0.0f;
+        const float wi = w_run + half_incl_scan_add(w, lane);
+        const float wti = wt_run + half_incl_scan_add(wt, lane);
+        float we = __shfl_up(wi, 1, 32), wte = __shfl_up(wti, 1, 32);
+        if (lane == 0) { we = w_run; wte = wt_run; }
+        if (valid) {
+            ws_inc[s] = wi; wts_inc[s] = wti;
+            acc += 2 * (wti * we - wi * wte) + 1.0f / 3 * w * w * deltas[s];
+        }
+        w_run = __shfl(wi, 31, 32); wt_run = __shfl(wti, 31, 32);
+    }
+    acc = half_sum(acc);
+    if (lane == 0) loss[(size_t)sg.ray] = acc;
+}
+
+__global__ void distortion_bw_kernel(const float* __restrict__ dL_dloss, const float* __restrict__ ws_inc,
+                                     const float* __restrict__ wts_inc, const float* __restrict__ ws,
+                                     const float* __restrict__ deltas, const float* __restrict__ ts,
+                                     const int64_t* __restrict__ rays_a, int n_rays, float* __restrict__ dL_dws)
+{
+    Seg sg; int lane;
+    if (!seg_load(rays_a, n_rays, sg, lane)) return;
+    if (sg.n <= 0) return; // the reference reads start-1 here (losses.cu:125-128)
+    const int64_t end = sg.start + sg.n - 1;
+    const float w_sum = ws_inc[end], wt_sum = wts_inc[end];
+    const float g = dL_dloss[(size_t)sg.ray];
+    for (int k = lane; k < sg.n; k += 32) {
+        const int64_t s = sg.start + k;
+        const float t = ts[s];
+        const float left = (k == 0) ? 0.0f : (t * ws_inc[s - 1] - wts_inc[s - 1]);
+        float v = g * 2 * (left + (wt_sum - wts_inc[s] - t * (w_sum - ws_inc[s])));
+        v += g * 2.0f / 3 * ws[s] * deltas[s];
+        dL_dws[s] = v;
+    }
+}
+
+// ------------------------------------------------------------------ segment_csr sum (R4)
+__global__ void segment_csr_kernel(const float* __restrict__ src, const int64_t* __restrict__ indptr, int n_seg,
+                                   int width, float* __restrict__ out)
+{
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int seg = gtid >> 5, lane = threadIdx.x & 31;
+    if (seg >= n_seg) return;
+    const int64_t b = indptr[seg], e = indptr[seg + 1];
+    for (int c = 0; c < width; c++) {
+        float a = 0.0f;
+        for (int64_t k = b + lane; k < e; k += 32) a += src[k * width + c];
+        a = half_sum(a);
+        if (lane == 0) out[(size_t)seg * width + c] = a;
+    }
+}
+
+inline dim3 seg_grid(int n_rays) { return dim3(ngp_blocks((int64_t)n_rays * 32, 256)); }
+
+} // namespace
+
+extern "C" {
+
+int ngp_composite_alpha_fw(const float* sigmas, const float* deltas, const int64_t* rays_a, float T_threshold,
+                           int n_rays, float* alphas, float* ws, void* stream)
+{
+    if (n_rays < 0) return NGP_EINVAL;
+    if (n_rays == 0) return NGP_OK;
+    if (!sigmas || !deltas || !rays_a || !alphas || !ws) return NGP_EINVAL;
+    hipLaunchKernelGGL(composite_alpha_fw_kernel, seg_grid(n_rays), dim3(256), 0, (hipStream_t)stream,
+                       sigmas, deltas, rays_a, T_threshold, n_rays, alphas, ws);
+    return ngp_check_launch();
+}
+
+int ngp_composite_train_fw(const float* sigmas, const float* rgbs, const float* normals_pred, const float* sems,
+                           const float* deltas, const float* ts, const int64_t* rays_a, float T_threshold,
+                           int classes, int n_rays, int64_t* total_samples, float* opacity, float* depth,
+                           float* rgb, float* normal_pred, float* sem, float* ws, void* stream)
+{
+    if (n_rays < 0 || classes < 0) return NGP_EINVAL;
+    if (n_rays == 0) return NGP_OK;
+    if (!rays_a || !total_samples || !opacity || !depth || !rgb || !normal_pred || (classes && !sem)) return NGP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_FW(CM, CL)                                                                                          \
+    hipLaunchKernelGGL(composite_train_fw_kernel<CM>, seg_grid(n_rays), dim3(256), 0, st, sigmas, rgbs,            \
+                       normals_pred, sems, deltas, ts, rays_a, T_threshold, CL, n_rays, total_samples, opacity,    \
+                       depth, rgb, normal_pred, sem, ws)
+    if (classes == 0) LAUNCH_FW(0, 0);
+    else if (classes <= 8) LAUNCH_FW(8, classes);
+    else if (classes <= 16) LAUNCH_FW(16, classes);
+    else if (classes <= 32) LAUNCH_FW(32, classes);
+    else {
+        LAUNCH_FW(0, 0);
+        hipLaunchKernelGGL(composite_sem_fw_kernel, seg_grid(n_rays), dim3(256), 0, st, ws, sems, rays_a, classes,
+                           n_rays, sem);
+    }
+#undef LAUNCH_FW
+    return ngp_check_launch();
+}
+
+int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, const float* dL_drgb,
+                           const float* dL_dnormal_pred, const float* dL_dsem, const float* dL_dws,
+                           const float* sigmas, const float* rgbs, const float* normals_pred, const float* ws,
+                           const float* deltas, const float* ts, const int64_t* rays_a, const float* opacity,
+                           const float* depth, const float* rgb, const float* normal_pred, float T_threshold,
+                           int classes, int n_rays, float* dL_dsigmas, float* dL_drgbs, float* dL_dnormals_pred,
+                           float* dL_dsems, void* stream)
+{
+    (void)normals_pred; (void)normal_pred;
+    if (n_rays < 0 || classes < 0) return NGP_EINVAL;
+    if (n_rays == 0) return NGP_OK;
+    if (!rays_a || !dL_dsigmas || !dL_drgbs || !dL_dnormals_pred || (classes && !dL_dsems)) return NGP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_BW(CM, CL)                                                                                          \
+    hipLaunchKernelGGL(composite_train_bw_kernel<CM>, seg_grid(n_rays), dim3(256), 0, st, dL_dopacity, dL_ddepth,  \
+                       dL_drgb, dL_dnormal_pred, dL_dsem, dL_dws, sigmas, rgbs, ws, deltas, ts, rays_a, opacity,   \
+                       depth, rgb, T_threshold, CL, n_rays, dL_dsigmas, dL_drgbs, dL_dnormals_pred, dL_dsems)
+    if (classes == 0) LAUNCH_BW(0, 0);
+    else if (classes <= 8) LAUNCH_BW(8, classes);
+    else if (classes <= 16) LAUNCH_BW(16, classes);
+    else if (classes <= 32) LAUNCH_BW(32, classes);
+    else {
+        // ws saved by the forward is exactly the effective weight (zero behind the stop)
+        LAUNCH_BW(0, 0);
+        hipLaunchKernelGGL(composite_sem_bw_kernel, seg_grid(n_rays), dim3(256), 0, st, dL_dsem, ws, rays_a, classes,
+                           n_rays, dL_dsems);
+    }
+#undef LAUNCH_BW
+    return ngp_check_launch();
+}
+
+int ngp_composite_test_fw(const float* sigmas, const float* rgbs, const float* normals, const float* normals_raw,
+                          const float* sems, const float* deltas, const float* ts, const float* hits_t,
+                          int64_t* alive_indices, float T_threshold, int classes, const int32_t* n_eff_samples,
+                          int n_alive, int n_samples, float* opacity, float* depth, float* rgb, float* normal,
+                          float* normal_raw, float* sem, void* stream)
+{
+    (void)hits_t;
+    if (n_alive < 0 || classes < 0 || n_samples < 1) return NGP_EINVAL;
+    if (n_alive == 0) return NGP_OK;
+    if (!sigmas || !rgbs || !normals || !normals_raw || !deltas || !ts || !alive_indices || !n_eff_samples ||
+        !opacity || !depth || !rgb || !normal || !normal_raw || (classes && (!sem || !sems))) return NGP_EINVAL;
+    hipLaunchKernelGGL(composite_test_fw_kernel, dim3(ngp_blocks(n_alive, 64)), dim3(64), 0, (hipStream_t)stream,
+                       sigmas, rgbs, normals, normals_raw, sems, deltas, ts, alive_indices, T_threshold, classes,
+                       n_eff_samples, n_alive, n_samples, opacity, depth, rgb, normal, normal_raw, sem);
+    return ngp_check_launch();
+}
+
+int ngp_composite_refloss_fw(const float* sigmas, const float* normals_diff, const float* normals_ori,
+                             const float* deltas, const float* ts, const int64_t* rays_a, float T_threshold,
+                             int n_rays, float* loss_o, float* loss_p, void* stream)
+{
+    (void)ts;
+    if (n_rays < 0) return NGP_EINVAL;
+    if (n_rays == 0) return NGP_OK;
+    if (!rays_a || !loss_o || !loss_p) return NGP_EINVAL;
+    hipLaunchKernelGGL(refloss_fw_kernel, seg_grid(n_rays), dim3(256), 0, (hipStream_t)stream, sigmas, normals_diff,
+                       normals_ori, deltas, rays_a, T_threshold, n_rays, loss_o, loss_p);
+    return ngp_check_launch();
+}
+
+int ngp_composite_refloss_bw(const float* dL_dloss_o, const float* dL_dloss_p, const float* sigmas,
+                             const float* normals_diff, const float* normals_ori, const float* deltas,
+                             const float* ts, const int64_t* rays_a, const float* loss_o, const float* loss_p,
+                             float T_threshold, int n_rays, float* dL_dsigmas, float* dL_dnormals_diff,
+                             float* dL_dnormals_ori, void* stream)
+{
+    (void)ts;
+    if (n_rays < 0) return NGP_EINVAL;
+    if (n_rays == 0) return NGP_OK;
+    if (!rays_a || !dL_dsigmas || !dL_dnormals_diff || !dL_dnormals_ori) return NGP_EINVAL;
+    hipLaunchKernelGGL(refloss_bw_kernel, seg_grid(n_rays), dim3(256), 0, (hipStream_t)stream, dL_dloss_o, dL_dloss_p,
+                       sigmas, normals_diff, normals_ori, deltas, rays_a, loss_o, loss_p, T_threshold, n_rays,
+                       dL_dsigmas, dL_dnormals_diff, dL_dnormals_ori);
+    return ngp_check_launch();
+}
+
+int ngp_distortion_loss_fw(const float* ws, const float* deltas, const float* ts, const int64_t* rays_a, int n_rays,
+                           float* loss, float* ws_inclusive_scan, float* wts_inclusive_scan, void* stream)
+{
+    if (n_rays < 0) return NGP_EINVAL;
+    if (n_rays == 0) return NGP_OK;
+    if (!rays_a || !loss || !ws_inclusive_scan || !wts_inclusive_scan) return NGP_EINVAL;
+    hipLaunchKernelGGL(distortion_fw_kernel, seg_grid(n_rays), dim3(256), 0, (hipStream_t)stream, ws, deltas, ts,
+                       rays_a, n_rays, loss, ws_inclusive_scan, wts_inclusive_scan);
+    return ngp_check_launch();
+}
+
+int ngp_distortion_loss_bw(const float* dL_dloss, const float* ws_inclusive_scan, const float* wts_inclusive_scan,
+                           const float* ws, const float* deltas, const float* ts, const int64_t* rays_a, int n_rays,
+                           float* dL_dws, void* stream)
+{
+    if (n_rays < 0) return NGP_EINVAL;
+    if (n_rays == 0) return NGP_OK;
+    if (!rays_a || !dL_dloss || !dL_dws) return NGP_EINVAL;
+    hipLaunchKernelGGL(distortion_bw_kernel, seg_grid(n_rays), dim3(256), 0, (hipStream_t)stream, dL_dloss,
+                       ws_inclusive_scan, wts_inclusive_scan, ws, deltas, ts, rays_a, n_rays, dL_dws);
+    return ngp_check_launch();
+}
+
+int ngp_segment_csr_sum(const float* src, const int64_t* indptr, int n_seg, int width, float* out, void* stream)
+{
+    if (n_seg < 0 || width < 1) return NGP_EINVAL;
+    if (n_seg == 0) return NGP_OK;
+    if (!indptr || !out) return NGP_EINVAL;
+    hipLaunchKernelGGL(segment_csr_kernel, seg_grid(n_seg), dim3(256), 0, (hipStream_t)stream, src, indptr, n_seg,
+                       width, out);
+    return ngp_check_launch();
+}
+
+} // extern "C"

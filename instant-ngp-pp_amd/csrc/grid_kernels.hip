@@ -1,0 +1,543 @@
+// Multiresolution hash grid (tcnn Grid/Hash encoding semantics) and the
+// spherical-harmonics direction encoding.
+//
+// Work decomposition (MI355X-first, not tcnn's level-per-blockIdx.y):
+//   an ITEM is one (sample, level) pair, items are numbered sample-major so the encoded output
+//   (n, L*F) is item-contiguous: item i owns floats [i*F, (i+1)*F).
+//   forward / input-grad: LPI = F/4 lanes per item, each lane moves one 16-byte quarter/half
+//     row per corner (`global_load_dwordx4`), so a wave's output store is one contiguous
+//     1 KiB run and every table access is a whole 16/32-byte row segment.
+//   param-grad: F lanes per item, one fp32 atomic per lane per corner, so each
+//     `global_atomic_add_f32` wave-instruction covers whole 32-byte rows (8 rows per
+//     instruction at F=8) — the shape the memory-side atomic units want (MI355X_MICROARCH
+//     "Global float atomics": one lane per row is ~17x slower than contiguous segments).
+//     Lanes whose upstream gradient is exactly zero (samples behind the early-termination
+//     point, volumerendering.cu:111) issue no atomics.
+#include "common.h"
+
+namespace {
+
+struct GridMeta {
+    uint32_t n_levels, n_features;
+    uint32_t offset[NGP_MAX_LEVELS];
+    uint32_t size[NGP_MAX_LEVELS];   // rows in the level
+    uint32_t res[NGP_MAX_LEVELS];
+    uint32_t flags[NGP_MAX_LEVELS];  // bit0: hashed, bit1: size is a power of two
+    float scale[NGP_MAX_LEVELS];
+};
+
+struct LevelInfo {
+    uint32_t offset, size, res, flags;
+    float scale;
+};
+
+__device__ __forceinline__ LevelInfo level_info(const GridMeta& m, uint32_t l)
+{
+    LevelInfo li;
+    li.offset = m.offset[l]; li.size = m.size[l]; li.res = m.res[l]; li.flags = m.flags[l]; li.scale = m.scale[l];
+    return li;
+}
+
+__device__ __forceinline__ uint32_t row_index(const LevelInfo& li, uint32_t x, uint32_t y, uint32_t z)
+{
+    uint32_t idx;
+    if (li.flags & 1u) {
+        idx = x ^ (y * 2654435761u) ^ (z * 805459861u);
+        idx = (li.flags & 2u) ? (idx & (li.size - 1u)) : (idx % li.size);
+    } else {
+        idx = x + y * li.res + z * li.res * li.res;
+        if (idx >= li.size) idx %= li.size;
+    }
+    return li.offset + idx;
+}
+
+struct Cell {
+    uint32_t g[3];
+    float w[3];
+};
+
+__device__ __forceinline__ Cell cell_of(const float* __restrict__ x, int64_t sample, float scale)
+{
+    Cell c;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float p = fmaf(scale, x[3 * sample + k], 0.5f);
+        const float fl = floorf(p);
+        c.g[k] = (uint32_t)(int)fl;
+        c.w[k] = p - fl;
+    }
+    return c;
+}
+
+template <int V> struct VecT;
+template <> struct VecT<1> { typedef float T; };
+template <> struct VecT<2> { typedef float2 T; };
+template <> struct VecT<4> { typedef float4 T; };
+
+template <int V> __device__ __forceinline__ void vec_fma(float (&acc)[V], float w, const typename VecT<V>::T& v);
+template <> __device__ __forceinline__ void vec_fma<1>(float (&acc)[1], float w, const float& v) { acc[0] = fmaf(w, v, acc[0]); }
+template <> __device__ __forceinline__ void vec_fma<2>(float (&acc)[2], float w, const float2& v)
+{
+    acc[0] = fmaf(w, v.x, acc[0]); acc[1] = fmaf(w, v.y, acc[1]);
+}
+template <> __device__ __forceinline__ void vec_fma<4>(float (&acc)[4], float w, const float4& v)
+{
+    acc[0] = fmaf(w, v.x, acc[0]); acc[1] = fmaf(w, v.y, acc[1]);
+    acc[2] = fmaf(w, v.z, acc[2]); acc[3] = fmaf(w, v.w, acc[3]);
+}
+template <int V> __device__ __forceinline__ float vec_dot(const float (&g)[V], const typename VecT<V>::T& a, const typename VecT<V>::T& b);
+template <> __device__ __forceinline__ float vec_dot<1>(const float (&g)[1], const float& a, const float& b) { return g[0] * (a - b); }
+template <> __device__ __forceinline__ float vec_dot<2>(const float (&g)[2], const float2& a, const float2& b)
+{
+    return g[0] * (a.x - b.x) + g[1] * (a.y - b.y);
+}
+template <> __device__ __forceinline__ float vec_dot<4>(const float (&g)[4], const float4& a, const float4& b)
+{
+    return g[0] * (a.x - b.x) + g[1] * (a.y - b.y) + g[2] * (a.z - b.z) + g[3] * (a.w - b.w);
+}
+
+// ------------------------------------------------------------------ forward (H1)
+template <int F>
+__global__ void __launch_bounds__(256) grid_fwd_kernel(GridMeta meta, const float* __restrict__ table,
+                                                       const float* __restrict__ x, int64_t n_items,
+                                                       float* __restrict__ y)
+{
+    constexpr int V = F >= 4 ? 4 : F;   // floats per lane
+    constexpr int LPI = F / V;          // lanes per item
+    typedef typename VecT<V>::T vec_t;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t item = tid / LPI;
+    const int sub = (int)(tid % LPI);
+    if (item >= n_items) return;
+    const uint32_t L = meta.n_levels;
+    const int64_t sample = item / L;
+    const uint32_t level = (uint32_t)(item - sample * L);
+    const LevelInfo li = level_info(meta, level);
+    const Cell c = cell_of(x, sample, li.scale);
+
+    uint32_t rows[8];
+    float wts[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t cx = k & 1, cy = (k >> 1) & 1, cz = (k >> 2) & 1;
+        rows[k] = row_index(li, c.g[0] + cx, c.g[1] + cy, c.g[2] + cz);
+        wts[k] = (cx ? c.w[0] : 1 - c.w[0]) * (cy ? c.w[1] : 1 - c.w[1]) * (cz ? c.w[2] : 1 - c.w[2]);
+    }
+    vec_t vals[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        vals[k] = *reinterpret_cast<const vec_t*>(table + (size_t)rows[k] * F + sub * V);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) acc[j] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) vec_fma<V>(acc, wts[k], vals[k]);
+    vec_t out;
+    float* o = reinterpret_cast<float*>(&out);
+#pragma unroll
+    for (int j = 0; j < V; j++) o[j] = acc[j];
+    *reinterpret_cast<vec_t*>(y + item * F + sub * V) = out;
+}
+
+// ------------------------------------------------------------------ param gradient (H2)
+template <int F>
+__global__ void __launch_bounds__(256) grid_bwd_param_kernel(GridMeta meta, const float* __restrict__ x,
+                                                             const float* __restrict__ dL_dy, int64_t n_items,
+                                                             float* __restrict__ dtable)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t item = tid / F;
+    const int f = (int)(tid % F);
+    if (item >= n_items) return;
+    const float g = dL_dy[item * F + f];
+    if (g == 0.0f) return; // adds nothing: skip the 8 atomics
+    const uint32_t L = meta.n_levels;
+    const int64_t sample = item / L;
+    const uint32_t level = (uint32_t)(item - sample * L);
+    const LevelInfo li = level_info(meta, level);
+    const Cell c = cell_of(x, sample, li.scale);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t cx = k & 1, cy = (k >> 1) & 1, cz = (k >> 2) & 1;
+        const uint32_t row = row_index(li, c.g[0] + cx, c.g[1] + cy, c.g[2] + cz);
+        const float w = (cx ? c.w[0] : 1 - c.w[0]) * (cy ? c.w[1] : 1 - c.w[1]) * (cz ? c.w[2] : 1 - c.w[2]);
+        atomicAdd(dtable + (size_t)row * F + f, w * g);
+    }
+}
+
+// ------------------------------------------------------------------ input gradient (H3)
+// GROUP = lanes that belong to one sample (L * LPI, a power of two <= 64): their partial
+// (dx,dy,dz) are summed with xor-shuffles and lane 0 of the group stores the result.
+template <int F, int GROUP>
+__global__ void __launch_bounds__(256) grid_bwd_input_kernel(GridMeta meta, const float* __restrict__ table,
+                                                             const float* __restrict__ x,
+                                                             const float* __restrict__ dL_dy, int64_t n_items,
+                                                             float* __restrict__ dL_dx)
+{
+    constexpr int V = F >= 4 ? 4 : F;
+    constexpr int LPI = F / V;
+    typedef typename VecT<V>::T vec_t;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t item = tid / LPI;
+    const int sub = (int)(tid % LPI);
+    const bool live = item < n_items;
+    const uint32_t L = meta.n_levels;
+    const int64_t sample = live ? item / L : 0;
+    float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+    if (live) {
+        const uint32_t level = (uint32_t)(item - sample * L);
+        const LevelInfo li = level_info(meta, level);
+        const Cell c = cell_of(x, sample, li.scale);
+        float go[V];
+        {
+            const vec_t gv = *reinterpret_cast<const vec_t*>(dL_dy + item * F + sub * V);
+            const float* gp = reinterpret_cast<const float*>(&gv);
+#pragma unroll
+            for (int j = 0; j < V; j++) go[j] = gp[j];
+        }
+        vec_t vals[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t cx = k & 1, cy = (k >> 1) & 1, cz = (k >> 2) & 1;
+            const uint32_t row = row_index(li, c.g[0] + cx, c.g[1] + cy, c.g[2] + cz);
+            vals[k] = *reinterpret_cast<const vec_t*>(table + (size_t)row * F + sub * V);
+        }
+        const float wx0 = 1 - c.w[0], wx1 = c.w[0], wy0 = 1 - c.w[1], wy1 = c.w[1], wz0 = 1 - c.w[2], wz1 = c.w[2];
+        // d/dx: pairs (k, k|1) over (y,z); d/dy: pairs (k, k|2) over (x,z); d/dz: pairs (k, k|4) over (x,y)
+        gx = wy0 * wz0 * vec_dot<V>(go, vals[1], vals[0]) + wy1 * wz0 * vec_dot<V>(go, vals[3], vals[2]) +
+             wy0 * wz1 * vec_dot<V>(go, vals[5], vals[4]) + wy1 * wz1 * vec_dot<V>(go, vals[7], vals[6]);
+        gy = wx0 * wz0 * vec_dot<V>(go, vals[2], vals[0]) + wx1 * wz0 * vec_dot<V>(go, vals[3], vals[1]) +
+             wx0 * wz1 * vec_dot<V>(go, vals[6], vals[4]) + wx1 * wz1 * vec_dot<V>(go, vals[7], vals[5]);
+        gz = wx0 * wy0 * vec_dot<V>(go, vals[4], vals[0]) + wx1 * wy0 * vec_dot<V>(go, vals[5], vals[1]) +
+             wx0 * wy1 * vec_dot<V>(go, vals[6], vals[2]) + wx1 * wy1 * vec_dot<V>(go, vals[7], vals[3]);
+        gx *= li.scale; gy *= li.scale; gz *= li.scale;
+    }
+#pragma unroll
+    for (int o = GROUP / 2; o > 0; o >>= 1) {
+        gx += __shfl_xor(gx, o, GROUP);
+        gy += __shfl_xor(gy, o, GROUP);
+        gz += __shfl_xor(gz, o, GROUP);
+    }
+    if (live && (threadIdx.x & (GROUP - 1)) == 0) {
+        dL_dx[3 * sample] = gx; dL_dx[3 * sample + 1] = gy; dL_dx[3 * sample + 2] = gz;
+    }
+}
+
+// Fallback for level counts whose group is not a power of two: one lane per sample.
+template <int F>
+__global__ void grid_bwd_input_serial_kernel(GridMeta meta, const float* __restrict__ table,
+                                             const float* __restrict__ x, const float* __restrict__ dL_dy,
+                                             int64_t n, float* __restrict__ dL_dx)
+{
+    const int64_t sample = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sample >= n) return;
+    float acc[3] = { 0, 0, 0 };
+    for (uint32_t level = 0; level < meta.n_levels; level++) {
+        const LevelInfo li = level_info(meta, level);
+        const Cell c = cell_of(x, sample, li.scale);
+        const float* go = dL_dy + (sample * meta.n_levels + level) * F;
+        for (int gd = 0; gd < 3; gd++) {
+            const int a = (gd + 1) % 3, b = (gd + 2) % 3;
+            for (int cc = 0; cc < 4; cc++) {
+                uint32_t q0[3], q1[3];
+                const int ca = cc & 1, cb = (cc >> 1) & 1;
+                const float wt = li.scale * (ca ? c.w[a] : 1 - c.w[a]) * (cb ? c.w[b] : 1 - c.w[b]);
+                q0[a] = q1[a] = c.g[a] + ca; q0[b] = q1[b] = c.g[b] + cb;
+                q0[gd] = c.g[gd]; q1[gd] = c.g[gd] + 1;
+                const float* r0 = table + (size_t)row_index(li, q0[0], q0[1], q0[2]) * F;
+                const float* r1 = table + (size_t)row_index(li, q1[0], q1[1], q1[2]) * F;
+                float dot = 0;
+                for (int f = 0; f < F; f++) dot += go[f] * (r1[f] - r0[f]);
+                acc[gd] += wt * dot;
+            }
+        }
+    }
+    dL_dx[3 * sample] = acc[0]; dL_dx[3 * sample + 1] = acc[1]; dL_dx[3 * sample + 2] = acc[2];
+}
+
+// ------------------------------------------------------------------ double backward (H4)
+// F lanes per item.  v = dLoss/d(dL_dx) (n,3).
+//   dtable[row(c)] += sum_d v_d * scale * (+/- prod_{d'!=d} w~) * dL_dy      (atomic)
+//   dL_ddLdy[f]     = sum_d v_d * scale * sum_c (+/- prod w~) * table[row(c)][f]
+template <int F>
+__global__ void __launch_bounds__(256) grid_bwd_bwd_input_kernel(GridMeta meta, const float* __restrict__ table,
+                                                                 const float* __restrict__ x,
+                                                                 const float* __restrict__ dL_dy,
+                                                                 const float* __restrict__ v, int64_t n_items,
+                                                                 float* __restrict__ dtable,
+                                                                 float* __restrict__ dL_ddLdy)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t item = tid / F;
+    const int f = (int)(tid % F);
+    if (item >= n_items) return;
+    const uint32_t L = meta.n_levels;
+    const int64_t sample = item / L;
+    const uint32_t level = (uint32_t)(item - sample * L);
+    const LevelInfo li = level_info(meta, level);
+    const Cell c = cell_of(x, sample, li.scale);
+    const float vx = v[3 * sample] * li.scale, vy = v[3 * sample + 1] * li.scale, vz = v[3 * sample + 2] * li.scale;
+    const float g = dL_dy[item * F + f];
+    float ddy = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t cx = k & 1, cy = (k >> 1) & 1, cz = (k >> 2) & 1;
+        const float wx = cx ? c.w[0] : 1 - c.w[0], wy = cy ? c.w[1] : 1 - c.w[1], wz = cz ? c.w[2] : 1 - c.w[2];
+        // derivative of the trilinear weight of corner k w.r.t. each coordinate
+        const float coef = vx * (cx ? 1.0f : -1.0f) * wy * wz + vy * (cy ? 1.0f : -1.0f) * wx * wz +
+                           vz * (cz ? 1.0f : -1.0f) * wx * wy;
+        const uint32_t row = row_index(li, c.g[0] + cx, c.g[1] + cy, c.g[2] + cz);
+        if (dL_ddLdy) ddy = fmaf(coef, table[(size_t)row * F + f], ddy);
+        if (dtable && g != 0.0f && coef != 0.0f) atomicAdd(dtable + (size_t)row * F + f, coef * g);
+    }
+    if (dL_ddLdy) dL_ddLdy[item * F + f] = ddy;
+}
+
+// ------------------------------------------------------------------ spherical harmonics (H5)
+__device__ __forceinline__ void sh_eval(float x, float y, float z, int degree, float* o)
+{
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    o[0] = 0.28209479177387814f;
+    if (degree <= 1) return;
+    o[1] = -0.48860251190291987f * y; o[2] = 0.48860251190291987f * z; o[3] = -0.48860251190291987f * x;
+    if (degree <= 2) return;
+    o[4] = 1.0925484305920792f * xy; o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz; o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    if (degree <= 3) return;
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+template <int DEG>
+__global__ void sh_fwd_kernel(const float* __restrict__ xin, int64_t n, float* __restrict__ y)
+{
+    constexpr int D = DEG * DEG;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float o[16];
+    sh_eval(xin[3 * i] * 2 - 1, xin[3 * i + 1] * 2 - 1, xin[3 * i + 2] * 2 - 1, DEG, o);
+#pragma unroll
+    for (int k = 0; k < D; k++) y[i * D + k] = o[k];
+}
+
+// dL_dx of the SH basis (includes the factor 2 of the [0,1] -> [-1,1] remap)
+template <int DEG>
+__global__ void sh_bwd_kernel(const float* __restrict__ xin, const float* __restrict__ dL_dy, int64_t n,
+                              float* __restrict__ dL_dx)
+{
+    constexpr int D = DEG * DEG;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xin[3 * i] * 2 - 1, y = xin[3 * i + 1] * 2 - 1, z = xin[3 * i + 2] * 2 - 1;
+    float g[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) g[k] = k < D ? dL_dy[i * D + k] : 0.0f;
+    float dx = 0, dy = 0, dz = 0;
+    if (DEG >= 2) {
+        dy += -0.48860251190291987f * g[1]; dz += 0.48860251190291987f * g[2]; dx += -0.48860251190291987f * g[3];
+    }
+    if (DEG >= 3) {
+        dx += 1.0925484305920792f * y * g[4];  dy += 1.0925484305920792f * x * g[4];
+        dy += -1.0925484305920792f * z * g[5]; dz += -1.0925484305920792f * y * g[5];
+        dz += 2 * 0.94617469575755997f * z * g[6];
+        dx += -1.0925484305920792f * z * g[7]; dz += -1.0925484305920792f * x * g[7];
+        dx += 2 * 0.54627421529603959f * x * g[8]; dy += -2 * 0.54627421529603959f * y * g[8];
+    }
+    if (DEG >= 4) {
+        const float x2 = x * x, y2 = y * y, z2 = z * z;
+        dx += 0.59004358992664352f * (-6.0f * x * y) * g[9];  dy += 0.59004358992664352f * (-3.0f * x2 + 3.0f * y2) * g[9];
+        dx += 2.8906114426405538f * y * z * g[10]; dy += 2.8906114426405538f * x * z * g[10]; dz += 2.8906114426405538f * x * y * g[10];
+        dy += 0.45704579946446572f * (1.0f - 5.0f * z2) * g[11]; dz += 0.45704579946446572f * y * (-10.0f * z) * g[11];
+        dz += 0.3731763325901154f * (15.0f * z2 - 3.0f) * g[12];
+        dx += 0.45704579946446572f * (1.0f - 5.0f * z2) * g[13]; dz += 0.45704579946446572f * x * (-10.0f * z) * g[13];
+        dx += 1.4453057213202769f * z * 2 * x * g[14]; dy += -1.4453057213202769f * z * 2 * y * g[14];
+        dz += 1.4453057213202769f * (x2 - y2) * g[14];
+        dx += 0.59004358992664352f * (-3.0f * x2 + 3.0f * y2) * g[15]; dy += 0.59004358992664352f * 6.0f * x * y * g[15];
+    }
+    dL_dx[3 * i] = 2 * dx; dL_dx[3 * i + 1] = 2 * dy; dL_dx[3 * i + 2] = 2 * dz;
+}
+
+bool make_meta(const ngp_grid_desc* d, GridMeta& m)
+{
+    if (!d || d->n_levels < 1 || d->n_levels > NGP_MAX_LEVELS) return false;
+    const uint32_t F = d->n_features;
+    if (!(F == 1 || F == 2 || F == 4 || F == 8)) return false;
+    m.n_levels = d->n_levels; m.n_features = F;
+    for (uint32_t l = 0; l < NGP_MAX_LEVELS; l++) {
+        m.offset[l] = 0; m.size[l] = 1; m.res[l] = 1; m.flags[l] = 0; m.scale[l] = 0;
+    }
+    for (uint32_t l = 0; l < d->n_levels; l++) {
+        const uint32_t size = d->offsets[l + 1] - d->offsets[l], res = d->resolution[l];
+        if (size == 0) return false;
+        // tcnn's index loop: accumulate dims while stride <= size; hashed iff size < final stride
+        uint64_t stride = 1;
+        for (int k = 0; k < 3 && stride <= size; k++) stride *= res;
+        uint32_t flags = 0;
+        if (size < stride) flags |= 1u;
+        if ((size & (size - 1)) == 0) flags |= 2u;
+        m.offset[l] = d->offsets[l]; m.size[l] = size; m.res[l] = res; m.flags[l] = flags; m.scale[l] = d->scale[l];
+    }
+    return true;
+}
+
+template <int F>
+void launch_bwd_input(const GridMeta& m, const float* table, const float* x, const float* dL_dy, int64_t n,
+                      float* dL_dx, hipStream_t st)
+{
+    constexpr int LPI = F >= 4 ? F / 4 : 1;
+    const int64_t n_items = n * m.n_levels;
+    const int group = (int)m.n_levels * LPI;
+    const dim3 grid(ngp_blocks(n_items * LPI, 256));
+#define BWD_IN(G) hipLaunchKernelGGL((grid_bwd_input_kernel<F, G>), grid, dim3(256), 0, st, m, table, x, dL_dy, n_items, dL_dx)
+    switch (group) {
+        case 1: BWD_IN(1); break;
+        case 2: BWD_IN(2); break;
+        case 4: BWD_IN(4); break;
+        case 8: BWD_IN(8); break;
+        case 16: BWD_IN(16); break;
+        case 32: BWD_IN(32); break;
+        case 64: BWD_IN(64); break;
+        default:
+            hipLaunchKernelGGL(grid_bwd_input_serial_kernel<F>, dim3(ngp_blocks(n, 256)), dim3(256), 0, st, m, table, x,
+                               dL_dy, n, dL_dx);
+    }
+#undef BWD_IN
+}
+
+} // namespace
+
+extern "C" {
+
+int64_t ngp_grid_layout(int n_levels, int n_features, int log2_hashmap_size, int base_resolution,
+                        double per_level_scale, ngp_grid_desc* d)
+{
+    if (!d || n_levels < 1 || n_levels > NGP_MAX_LEVELS || log2_hashmap_size < 1 || log2_hashmap_size > 31 ||
+        base_resolution < 1) return NGP_EINVAL;
+    if (!(n_features == 1 || n_features == 2 || n_features == 4 || n_features == 8)) return NGP_EINVAL;
+    d->n_levels = (uint32_t)n_levels; d->n_features = (uint32_t)n_features;
+    const float l2 = log2f((float)per_level_scale);
+    uint32_t off = 0;
+    for (int l = 0; l < n_levels; l++) {
+        const float sc = exp2f(l * l2) * base_resolution - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(sc) + 1;
+        const uint32_t cap = 1u << log2_hashmap_size;
+        const uint64_t dense = (uint64_t)res * res * res;
+        uint32_t p = dense > (uint64_t)0xFFFFFFF0u ? 0xFFFFFFF0u : (uint32_t)dense;
+        p = (p + 7u) / 8u * 8u;
+        if (p > cap) p = cap;
+        d->scale[l] = sc; d->resolution[l] = res; d->offsets[l] = off;
+        off += p;
+    }
+    d->offsets[n_levels] = off;
+    for (int l = n_levels; l < NGP_MAX_LEVELS; l++) { d->scale[l] = 0; d->resolution[l] = 0; d->offsets[l + 1] = off; }
+    return (int64_t)off * n_features;
+}
+
+#define GRID_DISPATCH_F(F_, CALL)            \
+    switch (F_) {                            \
+        case 1: { constexpr int F = 1; CALL; } break; \
+        case 2: { constexpr int F = 2; CALL; } break; \
+        case 4: { constexpr int F = 4; CALL; } break; \
+        case 8: { constexpr int F = 8; CALL; } break; \
+        default: return NGP_EINVAL;          \
+    }
+
+int ngp_grid_fwd(const ngp_grid_desc* desc, const float* table, const float* x, int64_t n, float* y, void* stream)
+{
+    GridMeta m;
+    if (!make_meta(desc, m) || n < 0) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!table || !x || !y) return NGP_EINVAL;
+    const int64_t n_items = n * m.n_levels;
+    hipStream_t st = (hipStream_t)stream;
+    GRID_DISPATCH_F(m.n_features, {
+        constexpr int LPI = F >= 4 ? F / 4 : 1;
+        hipLaunchKernelGGL(grid_fwd_kernel<F>, dim3(ngp_blocks(n_items * LPI, 256)), dim3(256), 0, st, m, table, x,
+                           n_items, y);
+    });
+    return ngp_check_launch();
+}
+
+int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* dL_dy, int64_t n, float* dtable,
+                       void* stream)
+{
+    GridMeta m;
+    if (!make_meta(desc, m) || n < 0) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!x || !dL_dy || !dtable) return NGP_EINVAL;
+    const int64_t n_items = n * m.n_levels;
+    hipStream_t st = (hipStream_t)stream;
+    GRID_DISPATCH_F(m.n_features, {
+        hipLaunchKernelGGL(grid_bwd_param_kernel<F>, dim3(ngp_blocks(n_items * F, 256)), dim3(256), 0, st, m, x,
+                           dL_dy, n_items, dtable);
+    });
+    return ngp_check_launch();
+}
+
+int ngp_grid_bwd_input(const ngp_grid_desc* desc, const float* table, const float* x, const float* dL_dy, int64_t n,
+                       float* dL_dx, void* stream)
+{
+    GridMeta m;
+    if (!make_meta(desc, m) || n < 0) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!table || !x || !dL_dy || !dL_dx) return NGP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    GRID_DISPATCH_F(m.n_features, { launch_bwd_input<F>(m, table, x, dL_dy, n, dL_dx, st); });
+    return ngp_check_launch();
+}
+
+int ngp_grid_bwd_bwd_input(const ngp_grid_desc* desc, const float* table, const float* x, const float* dL_dy,
+                           const float* dL_ddLdx, int64_t n, float* dtable, float* dL_ddLdy, void* stream)
+{
+    GridMeta m;
+    if (!make_meta(desc, m) || n < 0) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!table || !x || !dL_dy || !dL_ddLdx) return NGP_EINVAL;
+    const int64_t n_items = n * m.n_levels;
+    hipStream_t st = (hipStream_t)stream;
+    GRID_DISPATCH_F(m.n_features, {
+        hipLaunchKernelGGL(grid_bwd_bwd_input_kernel<F>, dim3(ngp_blocks(n_items * F, 256)), dim3(256), 0, st, m,
+                           table, x, dL_dy, dL_ddLdx, n_items, dtable, dL_ddLdy);
+    });
+    return ngp_check_launch();
+}
+
+int ngp_sh_fwd(const float* x, int64_t n, int degree, float* y, void* stream)
+{
+    if (n < 0 || degree < 1 || degree > 4) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!x || !y) return NGP_EINVAL;
+    const dim3 grid(ngp_blocks(n, 256));
+    hipStream_t st = (hipStream_t)stream;
+    switch (degree) {
+        case 1: hipLaunchKernelGGL(sh_fwd_kernel<1>, grid, dim3(256), 0, st, x, n, y); break;
+        case 2: hipLaunchKernelGGL(sh_fwd_kernel<2>, grid, dim3(256), 0, st, x, n, y); break;
+        case 3: hipLaunchKernelGGL(sh_fwd_kernel<3>, grid, dim3(256), 0, st, x, n, y); break;
+        default: hipLaunchKernelGGL(sh_fwd_kernel<4>, grid, dim3(256), 0, st, x, n, y); break;
+    }
+    return ngp_check_launch();
+}
+
+int ngp_sh_bwd_input(const float* x, const float* dL_dy, int64_t n, int degree, float* dL_dx, void* stream)
+{
+    if (n < 0 || degree < 1 || degree > 4) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!x || !dL_dy || !dL_dx) return NGP_EINVAL;
+    const dim3 grid(ngp_blocks(n, 256));
+    hipStream_t st = (hipStream_t)stream;
+    switch (degree) {
+        case 1: hipLaunchKernelGGL(sh_bwd_kernel<1>, grid, dim3(256), 0, st, x, dL_dy, n, dL_dx); break;
+        case 2: hipLaunchKernelGGL(sh_bwd_kernel<2>, grid, dim3(256), 0, st, x, dL_dy, n, dL_dx); break;
+        case 3: hipLaunchKernelGGL(sh_bwd_kernel<3>, grid, dim3(256), 0, st, x, dL_dy, n, dL_dx); break;
+        default: hipLaunchKernelGGL(sh_bwd_kernel<4>, grid, dim3(256), 0, st, x, dL_dy, n, dL_dx); break;
+    }
+    return ngp_check_launch();
+}
+
+} // extern "C"

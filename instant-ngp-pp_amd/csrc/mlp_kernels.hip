@@ -1,0 +1,488 @@
+// Small-MLP layers on the f32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains),
+// activation backward, fused Adam, sum of squares.
+//
+// One LDS-tiled GEMM template serves the three products a dense layer needs:
+//   FWD   y  (n, n_out) = act(x (n, n_in) . W^T + b)       A = x  [m][k],  B = W [n][k]
+//   DGRAD dx (n, n_in)  = dz (n, n_out) . W                A = dz [m][k],  B = W [k][n]
+//   WGRAD dW (n_out,n_in) += dz^T . x  (split over samples, fp32 atomics)
+//                                                          A = dz [k][m],  B = x [k][n]
+// Both operands are staged k-major in LDS (As[k][m], Bs[k][n]) so that an MFMA fragment read
+// is one conflict-free ds_read_b32 per lane: lane l of the 32x32x2 MFMA holds A[i=l&31][k=l>>5]
+// and B[k=l>>5][j=l&31]; C/D is col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5).
+// Layers with n_out <= 4 (the density head, networks.py:57) use VALU kernels instead.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
+
+struct GemmArgs {
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;
+    int64_t M, N, K;      // logical GEMM sizes
+    const float* bias;    // FWD only (may be null)
+    float* z_pre;         // FWD only: pre-activation copy, ld = N (may be null)
+    int act;
+    int64_t k_chunk;      // WGRAD: K range per blockIdx.z
+    int vecA, vecB;       // 16-byte vector loads legal for the operand
+};
+
+__device__ __forceinline__ float act_fwd(float v, int act)
+{
+    switch (act) {
+        case NGP_ACT_RELU: return v > 0.0f ? v : 0.0f;
+        case NGP_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        case NGP_ACT_SOFTPLUS: return v > 20.0f ? v : log1pf(__expf(v));
+        case NGP_ACT_EXP: return __expf(v);
+        default: return v;
+    }
+}
+
+constexpr int BK = 16;
+
+// rows x BK tile from a [row][k]-contiguous matrix into dst[k][row] (k-major, ld = LD)
+template <int ROWS, int LD>
+__device__ __forceinline__ void stage_transpose(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows,
+                                                int64_t k0, int64_t kend, bool vec, float* __restrict__ dst)
+{
+    const int t = threadIdx.x;
+    constexpr int PASSES = ROWS >= 64 ? ROWS / 64 : 1;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; pass++) {
+        const int row = (t >> 2) + pass * 64;
+        if (ROWS < 64 && row >= ROWS) break;
+        const int kq = (t & 3) * 4;
+        const int64_t gr = row0 + row, gk = k0 + kq;
+        float v[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if (gr < rows) {
+            const float* p = src + gr * ld + gk;
+            if (vec && gk + 3 < kend) {
+                const float4 q = *reinterpret_cast<const float4*>(p);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (gk + j < kend) v[j] = p[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) dst[(kq + j) * LD + row] = v[j];
+    }
+}
+
+// BK x COLS tile from a [k][col]-contiguous matrix into dst[k][col]
+template <int COLS, int LD>
+__device__ __forceinline__ void stage_direct(const float* __restrict__ src, int64_t ld, int64_t col0, int64_t cols,
+                                             int64_t k0, int64_t kend, bool vec, float* __restrict__ dst)
+{
+    constexpr int TPR = COLS / 4;          // threads per k-row
+    constexpr int RPP = 256 / TPR;         // k-rows per pass
+    const int t = threadIdx.x;
+    constexpr int PASSES = RPP >= BK ? 1 : BK / RPP;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; pass++) {
+        const int kr = t / TPR + pass * RPP;
+        if (RPP > BK && kr >= BK) break;
+        const int c4 = (t % TPR) * 4;
+        const int64_t gk = k0 + kr, gc = col0 + c4;
+        float v[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if (gk < kend) {
+            const float* p = src + gk * ld + gc;
+            if (vec && gc + 3 < cols) {
+                const float4 q = *reinterpret_cast<const float4*>(p);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (gc + j < cols) v[j] = p[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) dst[kr * LD + c4 + j] = v[j];
+    }
+}
+
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs p)
+{
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr int LDA = BM + 2, LDB = BN + 2;
+    __shared__ float As[BK * LDA];
+    __shared__ float Bs[BK * LDB];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
+    int64_t kbeg = 0, kend = p.K;
+    if (MODE == MODE_WGRAD) {
+        kbeg = (int64_t)blockIdx.z * p.k_chunk;
+        kend = kbeg + p.k_chunk < p.K ? kbeg + p.k_chunk : p.K;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int b = 0; b < TN; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        if (MODE == MODE_WGRAD) stage_direct<BM, LDA>(p.A, p.lda, m0, p.M, k0, kend, p.vecA, As);
+        else stage_transpose<BM, LDA>(p.A, p.lda, m0, p.M, k0, kend, p.vecA, As);
+        if (MODE == MODE_FWD) stage_transpose<BN, LDB>(p.B, p.ldb, n0, p.N, k0, kend, p.vecB, Bs);
+        else stage_direct<BN, LDB>(p.B, p.ldb, n0, p.N, k0, kend, p.vecB, Bs);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < BK / 2; s++) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++) a[tm] = As[(2 * s + lh) * LDA + (wm * TM + tm) * 32 + li];
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) b[tn] = Bs[(2 * s + lh) * LDB + (wn * TN + tn) * 32 + li];
+#pragma unroll
+            for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+                for (int tn = 0; tn < TN; tn++)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++) {
+            const int64_t n = n0 + (wn * TN + tn) * 32 + li;
+            if (n >= p.N) continue;
+            const float bv = (MODE == MODE_FWD && p.bias) ? p.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float v = acc[tm][tn][r];
+                if (MODE == MODE_FWD) {
+                    v += bv;
+                    if (p.z_pre) p.z_pre[m * p.N + n] = v;
+                    p.C[m * p.ldc + n] = act_fwd(v, p.act);
+                } else if (MODE == MODE_DGRAD) {
+                    p.C[m * p.ldc + n] = v;
+                } else {
+                    atomicAdd(p.C + m * p.ldc + n, v);
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------- skinny layers (n_out <= 4)
+// forward: one half-wave per sample row, lanes stride over k, dot product by xor-shuffle
+__global__ void skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int64_t ldw,
+                                  const float* __restrict__ b, int64_t n, int n_in, int n_out, int act,
+                                  float* __restrict__ y, int64_t ldy, float* __restrict__ z_pre)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int lane = threadIdx.x & 31;
+    if (row >= n) return;
+    float acc[4] = { 0, 0, 0, 0 };
+    for (int k = lane; k < n_in; k += 32) {
+        const float xv = x[row * ldx + k];
+#pragma unroll
+        for (int o = 0; o < 4; o++) if (o < n_out) acc[o] = fmaf(xv, W[o * ldw + k], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        if (o >= n_out) break;
+        float v = half_sum(acc[o]);
+        if (lane == 0) {
+            if (b) v += b[o];
+            if (z_pre) z_pre[row * n_out + o] = v;
+            y[row * ldy + o] = act_fwd(v, act);
+        }
+    }
+}
+
+__global__ void skinny_dgrad_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ W, int64_t ldw,
+                                    int64_t n, int n_in, int n_out, float* __restrict__ dx, int64_t lddx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * n_in) return;
+    const int64_t row = i / n_in;
+    const int k = (int)(i - row * n_in);
+    float v = 0.0f;
+    for (int o = 0; o < n_out; o++) v = fmaf(dz[row * lddz + o], W[o * ldw + k], v);
+    dx[row * lddx + k] = v;
+}
+
+// dW[o][k] += sum_rows dz[row][o]*x[row][k]; one block per chunk of rows, thread = k column
+__global__ void skinny_wgrad_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ x, int64_t ldx,
+                                    int64_t n, int n_in, int n_out, int rows_per_block, float* __restrict__ dW,
+                                    int64_t ldw)
+{
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    for (int k = threadIdx.x; k < n_in; k += blockDim.x) {
+        float acc[4] = { 0, 0, 0, 0 };
+        for (int64_t r = r0; r < r1; r++) {
+            const float xv = x[r * ldx + k];
+#pragma unroll
+            for (int o = 0; o < 4; o++) if (o < n_out) acc[o] = fmaf(dz[r * lddz + o], xv, acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < 4; o++) if (o < n_out) atomicAdd(dW + o * ldw + k, acc[o]);
+    }
+}
+
+// db[j] += sum_rows dz[row][j]
+__global__ void colsum_kernel(const float* __restrict__ dz, int64_t lddz, int64_t n, int n_out, int rows_per_block,
+                              float* __restrict__ db)
+{
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    for (int j = threadIdx.x; j < n_out; j += blockDim.x) {
+        float a = 0.0f;
+        for (int64_t r = r0; r < r1; r++) a += dz[r * lddz + j];
+        atomicAdd(db + j, a);
+    }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yz, int64_t count, int act,
+                               float* __restrict__ dz)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float g = dy[i];
+        float v;
+        switch (act) {
+            case NGP_ACT_RELU: v = yz[i] > 0.0f ? g : 0.0f; break;
+            case NGP_ACT_SIGMOID: { const float s = yz[i]; v = g * s * (1.0f - s); } break;
+            case NGP_ACT_SOFTPLUS: { const float z = yz[i]; v = z > 20.0f ? g : g / (1.0f + __expf(-z)); } break;
+            case NGP_ACT_EXP: v = g * yz[i]; break;
+            default: v = g;
+        }
+        dz[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- optimizer
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            int64_t n, float step_size, float beta1, float beta2, float eps, float bc2_sqrt,
+                            float weight_decay, const float* __restrict__ grad_scale, int zero_grad)
+{
+    const float gs = grad_scale ? *grad_scale : 1.0f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p); float4* g4 = reinterpret_cast<float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float gr = ga[j] * gs;
+            if (weight_decay != 0.0f) gr += weight_decay * pa[j];
+            ma[j] = ma[j] + (gr - ma[j]) * (1.0f - beta1);
+            va[j] = va[j] * beta2 + (1.0f - beta2) * gr * gr;
+            const float denom = sqrtf(va[j]) / bc2_sqrt + eps;
+            pa[j] = pa[j] - step_size * (ma[j] / denom);
+        }
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (zero_grad) g4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    // tail
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gr = g[i] * gs;
+        if (weight_decay != 0.0f) gr += weight_decay * p[i];
+        const float mn = m[i] + (gr - m[i]) * (1.0f - beta1);
+        const float vn = v[i] * beta2 + (1.0f - beta2) * gr * gr;
+        m[i] = mn; v[i] = vn;
+        p[i] = p[i] - step_size * (mn / (sqrtf(vn) / bc2_sqrt + eps));
+        if (zero_grad) g[i] = 0.0f;
+    }
+}
+
+__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out)
+{
+    __shared__ float part[4];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float a = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a = fmaf(x[i], x[i], a);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// coef = extra_scale * min(1, max_norm / (sqrt(sumsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float extra_scale,
+                                 float* __restrict__ coef)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float norm = sqrtf(*sumsq) * extra_scale;
+        float c = max_norm / (norm + 1e-6f);
+        if (c > 1.0f) c = 1.0f;
+        *coef = c * extra_scale;
+    }
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+} // namespace
+
+extern "C" {
+
+int ngp_linear_fwd(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* b, int64_t n, int n_in,
+                   int n_out, int activation, float* y, int64_t ldy, float* z_pre, void* stream)
+{
+    if (n < 0 || n_in < 1 || n_out < 1 || ldx < n_in || ldw < n_in || ldy < n_out) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!x || !W || !y) return NGP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_out <= 4) {
+        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(ngp_blocks(n * 32, 256)), dim3(256), 0, st, x, ldx, W, ldw, b, n,
+                           n_in, n_out, activation, y, ldy, z_pre);
+        return ngp_check_launch();
+    }
+    GemmArgs p{};
+    p.A = x; p.lda = ldx; p.B = W; p.ldb = ldw; p.C = y; p.ldc = ldy;
+    p.M = n; p.N = n_out; p.K = n_in; p.bias = b; p.z_pre = z_pre; p.act = activation; p.k_chunk = 0;
+    p.vecA = aligned16(x) && (ldx % 4 == 0); p.vecB = aligned16(W) && (ldw % 4 == 0);
+    if (n_out > 32) {
+        dim3 grid(ngp_blocks(n, 128), ngp_blocks(n_out, 128));
+        hipLaunchKernelGGL((gemm_kernel<MODE_FWD, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+    } else {
+        dim3 grid(ngp_blocks(n, 128), 1);
+        hipLaunchKernelGGL((gemm_kernel<MODE_FWD, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+    }
+    return ngp_check_launch();
+}
+
+int ngp_linear_bwd_input(const float* dz, int64_t lddz, const float* W, int64_t ldw, int64_t n, int n_in, int n_out,
+                         float* dx, int64_t lddx, void* stream)
+{
+    if (n < 0 || n_in < 1 || n_out < 1 || lddz < n_out || ldw < n_in || lddx < n_in) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!dz || !W || !dx) return NGP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_out <= 4) {
+        hipLaunchKernelGGL(skinny_dgrad_kernel, dim3(ngp_blocks(n * n_in, 256)), dim3(256), 0, st, dz, lddz, W, ldw, n,
+                           n_in, n_out, dx, lddx);
+        return ngp_check_launch();
+    }
+    GemmArgs p{};
+    p.A = dz; p.lda = lddz; p.B = W; p.ldb = ldw; p.C = dx; p.ldc = lddx;
+    p.M = n; p.N = n_in; p.K = n_out; p.act = 0; p.k_chunk = 0;
+    p.vecA = aligned16(dz) && (lddz % 4 == 0); p.vecB = aligned16(W) && (ldw % 4 == 0);
+    if (n_in > 32) {
+        dim3 grid(ngp_blocks(n, 128), ngp_blocks(n_in, 128));
+        hipLaunchKernelGGL((gemm_kernel<MODE_DGRAD, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+    } else {
+        dim3 grid(ngp_blocks(n, 128), 1);
+        hipLaunchKernelGGL((gemm_kernel<MODE_DGRAD, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+    }
+    return ngp_check_launch();
+}
+
+int ngp_linear_bwd_weight(const float* dz, int64_t lddz, const float* x, int64_t ldx, int64_t n, int n_in, int n_out,
+                          float* dW, int64_t ldw, float* db, void* stream)
+{
+    if (n < 0 || n_in < 1 || n_out < 1 || lddz < n_out || ldx < n_in || ldw < n_in) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!dz || !x || !dW) return NGP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (db) {
+        const int rpb = 1024;
+        hipLaunchKernelGGL(colsum_kernel, dim3(ngp_blocks(n, rpb)), dim3(n_out >= 128 ? 128 : 64), 0, st, dz, lddz, n,
+                           n_out, rpb, db);
+    }
+    if (n_out <= 4) {
+        const int rpb = 512;
+        hipLaunchKernelGGL(skinny_wgrad_kernel, dim3(ngp_blocks(n, rpb)), dim3(n_in >= 256 ? 256 : (n_in >= 128 ? 128 : 64)),
+                           0, st, dz, lddz, x, ldx, n, n_in, n_out, rpb, dW, ldw);
+        return ngp_check_launch();
+    }
+    GemmArgs p{};
+    p.A = dz; p.lda = lddz; p.B = x; p.ldb = ldx; p.C = dW; p.ldc = ldw;
+    p.M = n_out; p.N = n_in; p.K = n; p.act = 0;
+    p.vecA = aligned16(dz) && (lddz % 4 == 0); p.vecB = aligned16(x) && (ldx % 4 == 0);
+    // split the sample dimension so that ~1024 workgroups are in flight
+    const bool big_m = n_out > 32, big_n = n_in > 32;
+    const int64_t tiles = (int64_t)ngp_blocks(n_out, big_m ? 128 : 32) * ngp_blocks(n_in, big_n ? 128 : 32);
+    int64_t splits = 1024 / (tiles > 0 ? tiles : 1);
+    if (splits < 1) splits = 1;
+    int64_t chunk = (n + splits - 1) / splits;
+    chunk = (chunk + BK - 1) / BK * BK;
+    if (chunk < 256) chunk = 256;
+    splits = (n + chunk - 1) / chunk;
+    p.k_chunk = chunk;
+    if (big_m && big_n) {
+        dim3 grid(ngp_blocks(n_out, 128), ngp_blocks(n_in, 128), (unsigned)splits);
+        hipLaunchKernelGGL((gemm_kernel<MODE_WGRAD, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+    } else if (big_m) { // tall: 128 x 32 tiles
+        dim3 grid(ngp_blocks(n_out, 128), ngp_blocks(n_in, 32), (unsigned)splits);
+        hipLaunchKernelGGL((gemm_kernel<MODE_WGRAD, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+    } else if (big_n) { // wide: 32 x 128 tiles
+        dim3 grid(ngp_blocks(n_out, 32), ngp_blocks(n_in, 128), (unsigned)splits);
+        hipLaunchKernelGGL((gemm_kernel<MODE_WGRAD, 1, 4, 1, 1>), grid, dim3(256), 0, st, p);
+    } else {
+        dim3 grid(ngp_blocks(n_out, 64), ngp_blocks(n_in, 64), (unsigned)splits);
+        hipLaunchKernelGGL((gemm_kernel<MODE_WGRAD, 2, 2, 1, 1>), grid, dim3(256), 0, st, p);
+    }
+    return ngp_check_launch();
+}
+
+int ngp_act_bwd(const float* dy, const float* y_or_z, int64_t count, int activation, float* dz, void* stream)
+{
+    if (count < 0) return NGP_EINVAL;
+    if (count == 0) return NGP_OK;
+    if (!dy || !dz || (activation != NGP_ACT_NONE && !y_or_z)) return NGP_EINVAL;
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y_or_z, count,
+                       activation, dz);
+    return ngp_check_launch();
+}
+
+int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, const float* grad_scale, int zero_grad,
+                  void* stream)
+{
+    if (n < 0 || step < 1) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return NGP_EINVAL;
+    if (!aligned16(param) || !aligned16(grad) || !aligned16(exp_avg) || !aligned16(exp_avg_sq)) return NGP_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    int64_t blocks = ((n >> 2) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, step_size, beta1, beta2, eps, bc2_sqrt, weight_decay, grad_scale, zero_grad);
+    return ngp_check_launch();
+}
+
+int ngp_sumsq(const float* x, int64_t n, float* out, void* stream)
+{
+    if (n < 0 || !out) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!x) return NGP_EINVAL;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    return ngp_check_launch();
+}
+
+int ngp_clip_coef(const float* sumsq, float max_norm, float extra_scale, float* coef, void* stream)
+{
+    if (!sumsq || !coef) return NGP_EINVAL;
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq, max_norm, extra_scale, coef);
+    return ngp_check_launch();
+}
+
+const char* ngp_version(void) { return "ngp_hip 0.1 gfx950"; }
+
+} // extern "C"

@@ -1,0 +1,497 @@
+// Ray-side kernels: AABB / sphere intersection, morton + packbits, occupancy-grid helpers,
+// the training marcher (count -> scan -> expand) and the test-time marcher.
+//
+// Built with -ffp-contract=off: every expression keeps the reference's operation order
+// (raymarching.cu / intersection.cu) with one rounding per operation, so results are
+// bit-identical to oracle/ngp_oracle.c.
+#include "common.h"
+
+#define SQRT3F 1.73205080757f
+
+namespace {
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// ------------------------------------------------------------------ intersections (R1)
+// One lane per ray, serial loop over voxels (V is 1 on the hot path, rendering.py:29).
+// Hits are kept in registers for max_hits==1 and in the output row otherwise, then the
+// row is insertion-sorted ascending on t1 with unused (-1) slots first — the layout the
+// reference's torch::sort + gather produces (intersection.cu:94-97).
+template <bool SPHERE>
+__global__ void intersect_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                 const float* __restrict__ centers, const float* __restrict__ sizes,
+                                 int n_rays, int n_prims, int max_hits,
+                                 int32_t* __restrict__ hit_cnt, float* __restrict__ hits_t,
+                                 int64_t* __restrict__ hits_idx)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
+    const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    float* ht = hits_t + (size_t)r * max_hits * 2;
+    int64_t* hi = hits_idx + (size_t)r * max_hits;
+    for (int k = 0; k < max_hits; k++) { ht[2 * k] = -1.0f; ht[2 * k + 1] = -1.0f; hi[k] = -1; }
+    int cnt = 0;
+    for (int v = 0; v < n_prims; v++) {
+        float t1, t2;
+        if (SPHERE) {
+            const float cx = ox - centers[3 * v], cy = oy - centers[3 * v + 1], cz = oz - centers[3 * v + 2];
+            const float rad = sizes[v];
+            const float a = dx * dx + dy * dy + dz * dz;
+            const float half_b = dx * cx + dy * cy + dz * cz;
+            const float c = cx * cx + cy * cy + cz * cz - rad * rad;
+            const float disc = half_b * half_b - a * c;
+            t1 = -1.0f; t2 = -1.0f;
+            if (!(disc < 0)) {
+                const float sq = sqrtf(disc);
+                t1 = (-half_b - sq) / a; t2 = (-half_b + sq) / a;
+            }
+        } else {
+            const float cx = centers[3 * v], cy = centers[3 * v + 1], cz = centers[3 * v + 2];
+            const float hx = sizes[3 * v], hy = sizes[3 * v + 1], hz = sizes[3 * v + 2];
+            const float ax = (cx - hx - ox) * ix, bx = (cx + hx - ox) * ix;
+            const float ay = (cy - hy - oy) * iy, by = (cy + hy - oy) * iy;
+            const float az = (cz - hz - oz) * iz, bz = (cz + hz - oz) * iz;
+            t1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+            t2 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            if (t1 > t2) { t1 = -1.0f; t2 = -1.0f; }
+        }
+        if (t2 > 0) {
+            if (cnt < max_hits) { ht[2 * cnt] = fmaxf(t1, 0.0f); ht[2 * cnt + 1] = t2; hi[cnt] = v; }
+            cnt++;
+        }
+    }
+    hit_cnt[r] = cnt;
+    for (int i = 1; i < max_hits; i++) {
+        const float a = ht[2 * i], b = ht[2 * i + 1];
+        const int64_t v = hi[i];
+        int j = i - 1;
+        while (j >= 0 && ht[2 * j] > a) {
+            ht[2 * j + 2] = ht[2 * j]; ht[2 * j + 3] = ht[2 * j + 1]; hi[j + 1] = hi[j];
+            j--;
+        }
+        ht[2 * j + 2] = a; ht[2 * j + 3] = b; hi[j + 1] = v;
+    }
+}
+
+__global__ void clamp_near_kernel(float* __restrict__ hits_t, int n_rays, int max_hits, float near_d)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    float* p = hits_t + (size_t)r * max_hits * 2;
+    const float t1 = p[0];
+    if (t1 >= 0 && t1 < near_d) p[0] = near_d;
+}
+
+// ------------------------------------------------------------------ morton / packbits (O1)
+__device__ __forceinline__ uint32_t spread3(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton_enc(uint32_t x, uint32_t y, uint32_t z)
+{
+    return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+}
+__device__ __forceinline__ uint32_t compact3(uint32_t x)
+{
+    x &= 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+__global__ void morton_kernel(const int32_t* __restrict__ coords, int n, int32_t* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (int32_t)morton_enc((uint32_t)coords[3 * i], (uint32_t)coords[3 * i + 1], (uint32_t)coords[3 * i + 2]);
+}
+
+__global__ void morton_invert_kernel(const int32_t* __restrict__ idx, int n, int32_t* __restrict__ coords)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t v = idx[i];
+    coords[3 * i] = (int32_t)compact3((uint32_t)(v >> 0));
+    coords[3 * i + 1] = (int32_t)compact3((uint32_t)(v >> 1));
+    coords[3 * i + 2] = (int32_t)compact3((uint32_t)(v >> 2));
+}
+
+// one lane per output byte; the 8 floats of a byte are two 16-byte loads
+__global__ void packbits_kernel(const float4* __restrict__ grid, int n_bytes, float thr, uint8_t* __restrict__ bits)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_bytes) return;
+    const float4 a = grid[2 * (size_t)n], b = grid[2 * (size_t)n + 1];
+    uint32_t m = 0;
+    m |= (a.x > thr) ? 1u : 0u;   m |= (a.y > thr) ? 2u : 0u;
+    m |= (a.z > thr) ? 4u : 0u;   m |= (a.w > thr) ? 8u : 0u;
+    m |= (b.x > thr) ? 16u : 0u;  m |= (b.y > thr) ? 32u : 0u;
+    m |= (b.z > thr) ? 64u : 0u;  m |= (b.w > thr) ? 128u : 0u;
+    bits[n] = (uint8_t)m;
+}
+
+__global__ void cell_points_kernel(const int32_t* __restrict__ coords, const float* __restrict__ noise, int n3,
+                                   int G, float s, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    const float hgs = s / G;
+    const float c = (float)coords[i] / (float)(G - 1) * 2 - 1;
+    out[i] = c * (s - hgs) + (noise[i] * 2 - 1) * hgs;
+}
+
+__global__ void grid_ema_kernel(float* __restrict__ grid, const float* __restrict__ tmp, int n, float decay)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = grid[i];
+    if (!(g < 0)) grid[i] = fmaxf(g * decay, tmp[i]);
+}
+
+// ------------------------------------------------------------------ marcher (R3 / T1)
+__device__ __forceinline__ float step_dt(float t, float esf, int max_samples, int G, float scale)
+{
+    return clampf(t * esf, SQRT3F / max_samples, SQRT3F * 2 * scale / G);
+}
+__device__ __forceinline__ int mip_of_pos(float x, float y, float z, int cascades)
+{
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int e; frexpf(mx, &e);
+    return min(cascades - 1, max(0, e + 1));
+}
+__device__ __forceinline__ int mip_of_dt(float dt, int G, int cascades)
+{
+    int e; frexpf(dt * G, &e);
+    return min(cascades - 1, max(0, e));
+}
+
+struct MarchRay {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;
+};
+
+// One DDA decision at t (raymarching.cu:205-233).  Returns true when the cell is occupied
+// (t untouched, dt = the step to take), else advances t past the empty cell.
+__device__ __forceinline__ bool march_probe(const MarchRay& c, const uint8_t* __restrict__ bits, int cascades,
+                                            int G, uint32_t G3, float Ginv, float scale, float dt_scale, float esf,
+                                            int max_samples, float& t, float& x, float& y, float& z, float& dt)
+{
+    const float tt = t;
+    x = c.ox + tt * c.dx; y = c.oy + tt * c.dy; z = c.oz + tt * c.dz;
+    dt = step_dt(tt, esf, max_samples, G, dt_scale);
+    const int mip = max(mip_of_pos(x, y, z, cascades), mip_of_dt(dt, G, cascades));
+    const float bound = fminf(scalbnf(1.0f, mip - 1), scale);
+    const float binv = 1 / bound;
+    const int nx = (int)clampf(0.5f * (x * binv + 1) * G, 0.0f, G - 1.0f);
+    const int ny = (int)clampf(0.5f * (y * binv + 1) * G, 0.0f, G - 1.0f);
+    const int nz = (int)clampf(0.5f * (z * binv + 1) * G, 0.0f, G - 1.0f);
+    const uint32_t idx = (uint32_t)mip * G3 + morton_enc((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+    const bool occ = bits[idx >> 3] & (1u << (idx & 7u));
+    if (occ) return true;
+    const float tx = (((nx + 0.5f + 0.5f * copysignf(1.0f, c.dx)) * Ginv * 2 - 1) * bound - x) * c.ix;
+    const float ty = (((ny + 0.5f + 0.5f * copysignf(1.0f, c.dy)) * Ginv * 2 - 1) * bound - y) * c.iy;
+    const float tz = (((nz + 0.5f + 0.5f * copysignf(1.0f, c.dz)) * Ginv * 2 - 1) * bound - z) * c.iz;
+    const float t_target = tt + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    float tn = tt;
+    do { tn += step_dt(tn, esf, max_samples, G, dt_scale); } while (tn < t_target);
+    t = tn;
+    return false;
+}
+
+__device__ __forceinline__ MarchRay load_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d, size_t r)
+{
+    MarchRay c;
+    c.ox = rays_o[3 * r]; c.oy = rays_o[3 * r + 1]; c.oz = rays_o[3 * r + 2];
+    c.dx = rays_d[3 * r]; c.dy = rays_d[3 * r + 1]; c.dz = rays_d[3 * r + 2];
+    c.ix = 1.0f / c.dx; c.iy = 1.0f / c.dy; c.iz = 1.0f / c.dz;
+    return c;
+}
+
+// Pass 1: one lane per ray walks the occupancy bitfield ONCE, parks each accepted sample's t
+// in t_scratch[r*max_samples + k] (a lane's consecutive stores fall in the same L2 lines and
+// are merged there) and records the count.  The reference walks every ray twice.
+__global__ void march_count_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                   const float* __restrict__ hits_t, const uint8_t* __restrict__ bits,
+                                   int cascades, float scale, float esf, const float* __restrict__ noise,
+                                   int G, int max_samples, int n_rays,
+                                   float* __restrict__ t_scratch, int32_t* __restrict__ counts)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const MarchRay c = load_ray(rays_o, rays_d, r);
+    const uint32_t G3 = (uint32_t)G * G * G;
+    const float Ginv = 1.0f / G;
+    float t1 = hits_t[2 * r];
+    const float t2 = hits_t[2 * r + 1];
+    if (t1 >= 0) {
+        const float dt0 = step_dt(t1, esf, max_samples, G, scale);
+        t1 += dt0 * noise[r];
+    }
+    float t = t1; int n = 0;
+    float* ts = t_scratch + (size_t)r * max_samples;
+    while (0 <= t && t < t2 && n < max_samples) {
+        float x, y, z, dt;
+        const float tcur = t;
+        if (march_probe(c, bits, cascades, G, G3, Ginv, scale, scale, esf, max_samples, t, x, y, z, dt)) {
+            ts[n] = tcur;
+            t += dt; n++;
+        }
+    }
+    counts[r] = n;
+}
+
+// Pass 2: single workgroup, exclusive scan of the per-ray counts -> rays_a rows (ray order)
+// and the {total, n_rays} counter.
+__global__ void __launch_bounds__(1024) march_scan_kernel(const int32_t* __restrict__ counts, int n_rays,
+                                                          int64_t* __restrict__ rays_a, int32_t* __restrict__ counter)
+{
+    __shared__ int32_t wave_tot[16];
+    __shared__ int64_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n_rays; base += 1024) {
+        const int r = base + tid;
+        const int32_t c = r < n_rays ? counts[r] : 0;
+        int32_t v = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t u = __shfl_up(v, o, 64);
+            if (lane >= o) v += u;
+        }
+        if (lane == 63) wave_tot[wid] = v;
+        __syncthreads();
+        int32_t woff = 0;
+        for (int w = 0; w < wid; w++) woff += wave_tot[w];
+        const int64_t carry = carry_s;
+        if (r < n_rays) {
+            rays_a[3 * (size_t)r] = r;
+            rays_a[3 * (size_t)r + 1] = carry + woff + (v - c);
+            rays_a[3 * (size_t)r + 2] = c;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + v;
+        __syncthreads();
+    }
+    if (tid == 0) { counter[0] = (int32_t)carry_s; counter[1] = n_rays; }
+}
+
+// Pass 3: one wave per ray, lanes stride over the ray's samples: coalesced reads of the
+// parked t's and contiguous xyz/dir/delta/t writes.
+__global__ void march_expand_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                    const float* __restrict__ t_scratch, const int64_t* __restrict__ rays_a,
+                                    float esf, int G, float scale, int max_samples, int n_rays,
+                                    float* __restrict__ xyzs, float* __restrict__ dirs,
+                                    float* __restrict__ deltas, float* __restrict__ ts)
+{
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (r >= n_rays) return;
+    const int64_t start = rays_a[3 * (size_t)r + 1];
+    const int n = (int)rays_a[3 * (size_t)r + 2];
+    if (n == 0) return;
+    const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
+    const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
+    const float* tsrc = t_scratch + (size_t)r * max_samples;
+    for (int k = lane; k < n; k += 64) {
+        const float t = tsrc[k];
+        const int64_t s = start + k;
+        xyzs[3 * s] = ox + t * dx; xyzs[3 * s + 1] = oy + t * dy; xyzs[3 * s + 2] = oz + t * dz;
+        dirs[3 * s] = dx; dirs[3 * s + 1] = dy; dirs[3 * s + 2] = dz;
+        ts[s] = t;
+        deltas[s] = step_dt(t, esf, max_samples, G, scale);
+    }
+}
+
+// optional: zero rows [counter[0], capacity) like the reference's torch::zeros outputs
+__global__ void march_zero_tail_kernel(const int32_t* __restrict__ counter, int64_t capacity,
+                                       float* __restrict__ xyzs, float* __restrict__ dirs,
+                                       float* __restrict__ deltas, float* __restrict__ ts)
+{
+    const int64_t first = counter[0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = first * 3 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity * 3; i += stride) {
+        xyzs[i] = 0.0f; dirs[i] = 0.0f;
+    }
+    for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += stride) {
+        deltas[i] = 0.0f; ts[i] = 0.0f;
+    }
+}
+
+// Test-time marcher (raymarching.cu:353-403): one lane per alive ray, at most n_samples steps.
+// calc_dt receives `cascades` where `scale` is expected (raymarching.cu:370,399) — kept.
+__global__ void march_test_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                  float* __restrict__ hits_t, const int64_t* __restrict__ alive,
+                                  const uint8_t* __restrict__ bits, int cascades, float scale, float esf,
+                                  int G, int max_samples, int n_samples, int n_alive,
+                                  float* __restrict__ xyzs, float* __restrict__ dirs,
+                                  float* __restrict__ deltas, float* __restrict__ ts, int32_t* __restrict__ n_eff)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const size_t r = (size_t)alive[n];
+    const MarchRay c = load_ray(rays_o, rays_d, r);
+    const uint32_t G3 = (uint32_t)G * G * G;
+    const float Ginv = 1.0f / G;
+    float t = hits_t[2 * r];
+    const float t2 = hits_t[2 * r + 1];
+    int s = 0;
+    float t_resume = t; // t right after the last accepted sample (raymarching.cu:390)
+    while (t < t2 && s < n_samples) {
+        float x, y, z, dt;
+        const float tcur = t;
+        if (march_probe(c, bits, cascades, G, G3, Ginv, scale, (float)cascades, esf, max_samples, t, x, y, z, dt)) {
+            const size_t o = (size_t)n * n_samples + s;
+            xyzs[3 * o] = x; xyzs[3 * o + 1] = y; xyzs[3 * o + 2] = z;
+            dirs[3 * o] = c.dx; dirs[3 * o + 1] = c.dy; dirs[3 * o + 2] = c.dz;
+            ts[o] = tcur; deltas[o] = dt;
+            t += dt; s++;
+            t_resume = t;
+        }
+    }
+    if (s > 0) hits_t[2 * r] = t_resume;
+    n_eff[n] = s;
+}
+
+} // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+int ngp_ray_aabb_intersect(const float* rays_o, const float* rays_d, const float* centers,
+                           const float* half_sizes, int n_rays, int n_voxels, int max_hits,
+                           int32_t* hit_cnt, float* hits_t, int64_t* hits_idx, void* stream)
+{
+    if (n_rays < 0 || n_voxels < 0 || max_hits < 1) return NGP_EINVAL;
+    if (n_rays == 0) return NGP_OK;
+    if (!rays_o || !rays_d || !hit_cnt || !hits_t || !hits_idx || (n_voxels && (!centers || !half_sizes))) return NGP_EINVAL;
+    hipLaunchKernelGGL(intersect_kernel<false>, dim3(ngp_blocks(n_rays, 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays_o, rays_d, centers, half_sizes, n_rays, n_voxels, max_hits, hit_cnt, hits_t, hits_idx);
+    return ngp_check_launch();
+}
+
+int ngp_ray_sphere_intersect(const float* rays_o, const float* rays_d, const float* centers,
+                             const float* radii, int n_rays, int n_spheres, int max_hits,
+                             int32_t* hit_cnt, float* hits_t, int64_t* hits_idx, void* stream)
+{
+    if (n_rays < 0 || n_spheres < 0 || max_hits < 1) return NGP_EINVAL;
+    if (n_rays == 0) return NGP_OK;
+    if (!rays_o || !rays_d || !hit_cnt || !hits_t || !hits_idx || (n_spheres && (!centers || !radii))) return NGP_EINVAL;
+    hipLaunchKernelGGL(intersect_kernel<true>, dim3(ngp_blocks(n_rays, 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays_o, rays_d, centers, radii, n_rays, n_spheres, max_hits, hit_cnt, hits_t, hits_idx);
+    return ngp_check_launch();
+}
+
+int ngp_clamp_near(float* hits_t, int n_rays, int max_hits, float near_distance, void* stream)
+{
+    if (n_rays < 0 || max_hits < 1) return NGP_EINVAL;
+    if (n_rays == 0) return NGP_OK;
+    if (!hits_t) return NGP_EINVAL;
+    hipLaunchKernelGGL(clamp_near_kernel, dim3(ngp_blocks(n_rays, 256)), dim3(256), 0, (hipStream_t)stream,
+                       hits_t, n_rays, max_hits, near_distance);
+    return ngp_check_launch();
+}
+
+int ngp_morton3D(const int32_t* coords, int n, int32_t* indices, void* stream)
+{
+    if (n < 0) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!coords || !indices) return NGP_EINVAL;
+    hipLaunchKernelGGL(morton_kernel, dim3(ngp_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, coords, n, indices);
+    return ngp_check_launch();
+}
+
+int ngp_morton3D_invert(const int32_t* indices, int n, int32_t* coords, void* stream)
+{
+    if (n < 0) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!coords || !indices) return NGP_EINVAL;
+    hipLaunchKernelGGL(morton_invert_kernel, dim3(ngp_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, indices, n, coords);
+    return ngp_check_launch();
+}
+
+int ngp_packbits(const float* density_grid, int n_bytes, float threshold, uint8_t* density_bitfield, void* stream)
+{
+    if (n_bytes < 0) return NGP_EINVAL;
+    if (n_bytes == 0) return NGP_OK;
+    if (!density_grid || !density_bitfield || ((uintptr_t)density_grid & 15)) return NGP_EINVAL;
+    hipLaunchKernelGGL(packbits_kernel, dim3(ngp_blocks(n_bytes, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)density_grid, n_bytes, threshold, density_bitfield);
+    return ngp_check_launch();
+}
+
+int ngp_grid_cell_points(const int32_t* coords, const float* noise, int n, int grid_size, float s,
+                         float* xyzs_w, void* stream)
+{
+    if (n < 0 || grid_size < 2) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!coords || !noise || !xyzs_w) return NGP_EINVAL;
+    hipLaunchKernelGGL(cell_points_kernel, dim3(ngp_blocks((int64_t)n * 3, 256)), dim3(256), 0, (hipStream_t)stream,
+                       coords, noise, n * 3, grid_size, s, xyzs_w);
+    return ngp_check_launch();
+}
+
+int ngp_density_grid_ema(float* density_grid, const float* density_grid_tmp, int n, float decay, void* stream)
+{
+    if (n < 0) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!density_grid || !density_grid_tmp) return NGP_EINVAL;
+    hipLaunchKernelGGL(grid_ema_kernel, dim3(ngp_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       density_grid, density_grid_tmp, n, decay);
+    return ngp_check_launch();
+}
+
+int ngp_raymarching_train(const float* rays_o, const float* rays_d, const float* hits_t,
+                          const uint8_t* density_bitfield, int cascades, float scale,
+                          float exp_step_factor, const float* noise, int grid_size,
+                          int max_samples, int n_rays,
+                          float* t_scratch, int32_t* ray_counts,
+                          int64_t* rays_a, float* xyzs, float* dirs, float* deltas, float* ts,
+                          int32_t* counter, int64_t sample_capacity, int zero_tail, void* stream)
+{
+    if (n_rays < 0 || cascades < 1 || grid_size < 1 || grid_size > 1024 || max_samples < 1) return NGP_EINVAL;
+    if (!counter) return NGP_EINVAL;
+    if (n_rays > 0 && (!rays_o || !rays_d || !hits_t || !density_bitfield || !noise || !t_scratch || !ray_counts ||
+                       !rays_a || !xyzs || !dirs || !deltas || !ts)) return NGP_EINVAL;
+    if (sample_capacity < (int64_t)n_rays * max_samples) return NGP_EINVAL; // worst case must fit
+    hipStream_t st = (hipStream_t)stream;
+    if (n_rays > 0)
+        hipLaunchKernelGGL(march_count_kernel, dim3(ngp_blocks(n_rays, 64)), dim3(64), 0, st,
+                           rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, noise,
+                           grid_size, max_samples, n_rays, t_scratch, ray_counts);
+    hipLaunchKernelGGL(march_scan_kernel, dim3(1), dim3(1024), 0, st, ray_counts, n_rays, rays_a, counter);
+    if (n_rays > 0)
+        hipLaunchKernelGGL(march_expand_kernel, dim3(ngp_blocks((int64_t)n_rays * 64, 256)), dim3(256), 0, st,
+                           rays_o, rays_d, t_scratch, rays_a, exp_step_factor, grid_size, scale, max_samples, n_rays,
+                           xyzs, dirs, deltas, ts);
+    if (zero_tail && sample_capacity > 0)
+        hipLaunchKernelGGL(march_zero_tail_kernel, dim3(2048), dim3(256), 0, st, counter, sample_capacity,
+                           xyzs, dirs, deltas, ts);
+    return ngp_check_launch();
+}
+
+int ngp_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t,
+                         const int64_t* alive_indices, const uint8_t* density_bitfield,
+                         int cascades, float scale, float exp_step_factor, int grid_size,
+                         int max_samples, int n_samples, int n_alive,
+                         float* xyzs, float* dirs, float* deltas, float* ts,
+                         int32_t* n_eff_samples, void* stream)
+{
+    if (n_alive < 0 || cascades < 1 || grid_size < 1 || grid_size > 1024 || n_samples < 1) return NGP_EINVAL;
+    if (n_alive == 0) return NGP_OK;
+    if (!rays_o || !rays_d || !hits_t || !alive_indices || !density_bitfield || !xyzs || !dirs || !deltas || !ts ||
+        !n_eff_samples) return NGP_EINVAL;
+    hipLaunchKernelGGL(march_test_kernel, dim3(ngp_blocks(n_alive, 64)), dim3(64), 0, (hipStream_t)stream,
+                       rays_o, rays_d, hits_t, alive_indices, density_bitfield, cascades, scale, exp_step_factor,
+                       grid_size, max_samples, n_samples, n_alive, xyzs, dirs, deltas, ts, n_eff_samples);
+    return ngp_check_launch();
+}
+
+} // extern "C"

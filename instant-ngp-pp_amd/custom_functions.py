@@ -1,0 +1,201 @@
+"""Operator surface of the reference (models/custom_functions.py) — same class names, argument
+order and return values — on the MI355X library.
+
+RayAABBIntersector :9   RaySphereIntersector :33   RayMarcher :56   VolumeRenderer :117
+RefLoss :165   TruncExp :200   ReLU :213   TruncTanh :231   sample_pdf :248   raw2outputs :280
+"""
+import torch
+
+from . import vren
+from ._lib import call
+from .torch_scatter import segment_csr
+
+_f32 = torch.float32
+
+
+class RayAABBIntersector(torch.autograd.Function):
+    """rays_o, rays_d (N_rays,3); center, half_size (N_voxels,3); max_hits
+    -> hits_cnt (N_rays), hits_t (N_rays,max_hits,2) near->far (-1 = no hit), hits_voxel_idx"""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, center, half_size, max_hits):
+        return tuple(vren.ray_aabb_intersect(rays_o, rays_d, center, half_size, max_hits))
+
+
+class RaySphereIntersector(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, center, radii, max_hits):
+        return tuple(vren.ray_sphere_intersect(rays_o, rays_d, center, radii, max_hits))
+
+
+class RayMarcher(torch.autograd.Function):
+    """March the rays through the occupancy bitfield.
+    -> rays_a (N_rays,3) [ray_idx, start_idx, N_samples], xyzs (N,3), dirs (N,3), deltas (N), ts (N),
+       total_samples (0-dim int32 tensor)
+
+    rays_a rows come out in ray order with monotone start indices (the reference's order is
+    whatever its atomics produce, raymarching.cu:237-241), which also makes backward()'s CSR
+    segments valid by construction."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, grid_size,
+                max_samples):
+        noise = torch.rand_like(rays_o[:, 0])  # perturbs the first sample of each ray
+        rays_a, xyzs, dirs, deltas, ts, counter = vren.raymarching_train_untrimmed(
+            rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, noise, grid_size, max_samples)
+        total_samples = counter[0]
+        n = int(total_samples)  # the one host sync of the step (the reference has the same, §3.1)
+        xyzs, dirs, deltas, ts = xyzs[:n], dirs[:n], deltas[:n], ts[:n]
+        ctx.save_for_backward(rays_a, ts)
+        return rays_a, xyzs, dirs, deltas, ts, total_samples
+
+    @staticmethod
+    def backward(ctx, dL_drays_a, dL_dxyzs, dL_ddirs, dL_ddeltas, dL_dts, dL_dtotal_samples):
+        rays_a, ts = ctx.saved_tensors
+        segments = torch.cat([rays_a[:, 1], rays_a[-1:, 1] + rays_a[-1:, 2]])
+        dL_drays_o = segment_csr(dL_dxyzs.contiguous(), segments)
+        dL_drays_d = segment_csr((dL_dxyzs * ts[:, None] + dL_ddirs).contiguous(), segments)
+        return dL_drays_o, dL_drays_d, None, None, None, None, None, None, None
+
+
+class VolumeRenderer(torch.autograd.Function):
+    """Front-to-back compositing with a variable number of samples per ray (training only).
+    -> vr_samples (scalar), opacity (N_rays), depth (N_rays), rgb (N_rays,3), normal_pred (N_rays,3),
+       sem (N_rays,classes), ws (N)"""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, normals_pred, sems, deltas, ts, rays_a, T_threshold, classes):
+        nr, N = rays_a.shape[0], sigmas.shape[0]
+        dev = sigmas.device
+        total = torch.empty(nr, dtype=torch.int64, device=dev)
+        opacity = torch.empty(nr, dtype=_f32, device=dev)
+        depth = torch.empty(nr, dtype=_f32, device=dev)
+        rgb = torch.empty(nr, 3, dtype=_f32, device=dev)
+        normal_pred = torch.empty(nr, 3, dtype=_f32, device=dev)
+        sem = torch.empty(nr, classes, dtype=_f32, device=dev)
+        ws = torch.empty(N, dtype=_f32, device=dev)  # every row is covered by the marcher's rays_a
+        call("composite_train_fw", sigmas, rgbs, normals_pred, sems, deltas, ts, rays_a, float(T_threshold),
+             int(classes), nr, total, opacity, depth, rgb, normal_pred, sem, ws)
+        ctx.save_for_backward(sigmas, rgbs, normals_pred, deltas, ts, rays_a, opacity, depth, rgb, normal_pred, ws)
+        ctx.T_threshold = T_threshold
+        ctx.classes = classes
+        return total.sum(), opacity, depth, rgb, normal_pred, sem, ws
+
+    @staticmethod
+    def backward(ctx, dL_dtotal_samples, dL_dopacity, dL_ddepth, dL_drgb, dL_dnormal_pred, dL_dsem, dL_dws):
+        sigmas, rgbs, normals_pred, deltas, ts, rays_a, opacity, depth, rgb, normal_pred, ws = ctx.saved_tensors
+        N, classes = sigmas.shape[0], ctx.classes
+        dev = sigmas.device
+        d_sig = torch.empty(N, dtype=_f32, device=dev)
+        d_rgbs = torch.empty(N, 3, dtype=_f32, device=dev)
+        d_nrm = torch.empty(N, 3, dtype=_f32, device=dev)
+        d_sems = torch.empty(N, classes, dtype=_f32, device=dev)
+        call("composite_train_bw", dL_dopacity.contiguous(), dL_ddepth.contiguous(), dL_drgb.contiguous(),
+             dL_dnormal_pred.contiguous(), dL_dsem.contiguous(), dL_dws.contiguous(), sigmas, rgbs, normals_pred, ws,
+             deltas, ts, rays_a, opacity, depth, rgb, normal_pred, float(ctx.T_threshold), int(classes),
+             rays_a.shape[0], d_sig, d_rgbs, d_nrm, d_sems)
+        return d_sig, d_rgbs, d_nrm, d_sems, None, None, None, None, None
+
+
+class RefLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sigmas, normals_diff, normals_ori, deltas, ts, rays_a, T_threshold):
+        loss_o, loss_p = vren.composite_refloss_fw(sigmas, normals_diff, normals_ori, deltas, ts, rays_a, T_threshold)
+        ctx.save_for_backward(sigmas, normals_diff, normals_ori, deltas, ts, rays_a, loss_o, loss_p)
+        ctx.T_threshold = T_threshold
+        return loss_o, loss_p
+
+    @staticmethod
+    def backward(ctx, dL_dloss_o, dL_dloss_p):
+        sigmas, normals_diff, normals_ori, deltas, ts, rays_a, loss_o, loss_p = ctx.saved_tensors
+        dL_dsigmas, dL_dnormals_diff, dL_dnormals_ori = vren.composite_refloss_bw(
+            dL_dloss_o.contiguous(), dL_dloss_p.contiguous(), sigmas, normals_diff, normals_ori, deltas, ts, rays_a,
+            loss_o, loss_p, ctx.T_threshold)
+        # the reference discards dL_dsigmas here (custom_functions.py:198)
+        return None, dL_dnormals_diff, dL_dnormals_ori, None, None, None, None
+
+
+class TruncExp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, dL_dout):
+        x = ctx.saved_tensors[0]
+        return dL_dout * torch.exp(x.clamp(-7, 7))
+
+
+class ReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        mask = x > 0
+        ctx.save_for_backward(mask)
+        return torch.where(mask, x, torch.zeros_like(x))
+
+    @staticmethod
+    def backward(ctx, dL_dout):
+        (mask,) = ctx.saved_tensors
+        # masked-out entries get 1e-6, as the reference (custom_functions.py:227)
+        return torch.where(mask, dL_dout, torch.full_like(dL_dout, 1e-6))
+
+
+class TruncTanh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.tanh(x)
+
+    @staticmethod
+    def backward(ctx, dL_dout):
+        x = ctx.saved_tensors[0]
+        return dL_dout * (1 - torch.tanh(x.clamp(-15, 15)) ** 2)
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    """Hierarchical sampling (custom_functions.py:248-278)."""
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if det:
+        u = torch.linspace(0., 1., steps=N_samples, device=cdf.device)
+        u = u.expand(list(cdf.shape[:-1]) + [N_samples])
+    else:
+        u = torch.rand(list(cdf.shape[:-1]) + [N_samples], device=cdf.device)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.clamp(inds - 1, min=0)
+    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
+    cdf_g0, cdf_g1 = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)
+    bins_g0, bins_g1 = torch.gather(bins, -1, below), torch.gather(bins, -1, above)
+    denom = cdf_g1 - cdf_g0
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_g0) / denom
+    return bins_g0 + t * (bins_g1 - bins_g0)
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, classes=7):
+    """Dense-sample compositing (custom_functions.py:280-321)."""
+    sigmas = raw[..., 0]
+    rgbs = raw[..., 1:4]
+    normals_raw = raw[..., 4:7]
+    normals_pred = raw[..., 7:10]
+    sems = raw[..., 10:]
+    dists = z_vals[..., 1:] - z_vals[..., :-1]
+    dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], -1)
+    dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
+    noise = 0.
+    if raw_noise_std > 0.:
+        noise = torch.randn(sigmas.shape, device=raw.device) * raw_noise_std
+    alpha = 1. - torch.exp(-(sigmas + noise) * dists)
+    ones = torch.ones((alpha.shape[0], 1), device=raw.device)
+    weights = alpha * torch.cumprod(torch.cat([ones, 1. - alpha + 1e-10], -1), -1)[:, :-1]
+    opacity = torch.sum(weights, -1)
+    rgb_map = torch.sum(weights[..., None] * rgbs, -2)
+    normal_raw = torch.sum(weights[..., None] * normals_raw, -2)
+    normal_pred = torch.sum(weights[..., None] * normals_pred, -2)
+    sem = torch.sum(weights[..., None] * sems, -2)
+    depth_map = torch.sum(weights * z_vals, -1)
+    return opacity, rgb_map, normal_raw, normal_pred, sem, weights, depth_map

@@ -1,0 +1,112 @@
+"""Loss terms of the reference (losses.py:7-151) on the MI355X operator surface."""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import vren
+
+
+def compute_scale_and_shift(prediction, target):
+    """least-squares scale/shift aligning prediction to target (losses.py:7-30)"""
+    a_00 = torch.sum(prediction * prediction)
+    a_01 = torch.sum(prediction)
+    a_11 = torch.sum(torch.ones_like(prediction))
+    b_0 = torch.sum(prediction * target)
+    b_1 = torch.sum(target)
+    det = a_00 * a_11 - a_01 * a_01
+    if det != 0:
+        x_0 = (a_11 * b_0 - a_01 * b_1) / det
+        x_1 = (-a_01 * b_0 + a_00 * b_1) / det
+    else:
+        x_0 = torch.zeros((), device=prediction.device)
+        x_1 = torch.zeros((), device=prediction.device)
+    return x_0, x_1
+
+
+class DistortionLoss(torch.autograd.Function):
+    """Mip-NeRF 360 distortion loss in DVGO-v2's prefix-sum form (losses.py:32-58).
+    ws, deltas, ts (N); rays_a (N_rays,3) -> loss (N_rays)"""
+
+    @staticmethod
+    def forward(ctx, ws, deltas, ts, rays_a):
+        loss, ws_inclusive_scan, wts_inclusive_scan = vren.distortion_loss_fw(ws.contiguous(), deltas, ts, rays_a)
+        ctx.save_for_backward(ws_inclusive_scan, wts_inclusive_scan, ws, deltas, ts, rays_a)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dL_dloss):
+        ws_inclusive_scan, wts_inclusive_scan, ws, deltas, ts, rays_a = ctx.saved_tensors
+        dL_dws = vren.distortion_loss_bw(dL_dloss.contiguous(), ws_inclusive_scan, wts_inclusive_scan,
+                                         ws.contiguous(), deltas, ts, rays_a)
+        return dL_dws, None, None, None
+
+
+class ExponentialAnnealingWeight():
+    def __init__(self, max, min, k):
+        self.max, self.min, self.k = max, min, k
+
+    def getWeight(self, Tcur):
+        return max(self.min, self.max * math.exp(-Tcur * self.k))
+
+
+class NeRFLoss(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.lambda_opa = 2e-4
+        self.lambda_distortion = 3e-4
+        self.lambda_depth_mono = 1
+        self.lambda_normal_mono = 1e-3
+        self.lambda_normal_ref_rp = 1e-3
+        self.lambda_normal_ref_ro = 1e-3
+        self.lambda_sky = 1e-1
+        self.lambda_semantic = 4e-2
+        self.Annealing = ExponentialAnnealingWeight(max=1, min=6e-2, k=1e-3)
+        self.CrossEntropyLoss = nn.CrossEntropyLoss(ignore_index=256)
+
+    def forward(self, results, target, **kwargs):
+        d = {}
+        if kwargs.get('embed_msk', False):
+            d['r_ms'], _ = self.mask_regularize(kwargs['mask'], self.Annealing.getWeight(kwargs['step']), 0)
+            d['rgb'] = (1 - kwargs['mask']) * (results['rgb'] - target['rgb']) ** 2
+        else:
+            d['rgb'] = (results['rgb'] - target['rgb']) ** 2
+
+        o = results['opacity'] + 1e-10
+        d['opacity'] = self.lambda_opa * (-o * torch.log(o))  # push opacity towards 0 or 1
+
+        if self.lambda_distortion > 0:
+            d['distortion'] = self.lambda_distortion * \
+                DistortionLoss.apply(results['ws'], results['deltas'], results['ts'], results['rays_a'])
+
+        if kwargs.get('normal_ref', False):
+            d['normal_ref_rp'] = self.lambda_normal_ref_rp * results['Rp']
+            d['normal_ref_ro'] = self.lambda_normal_ref_ro * results['Ro']
+
+        if kwargs.get('normal_mono', False):
+            normal_pred = F.normalize(results['normal_pred'], dim=-1)
+            normal_gt = F.normalize(target['normal'], dim=-1)
+            d['normal_mono'] = self.lambda_normal_mono * \
+                (torch.abs(normal_pred - normal_gt) + 0.1 * (-(normal_pred * normal_gt)))
+
+        if kwargs.get('semantic', False):
+            d['CELoss'] = self.lambda_semantic * self.CrossEntropyLoss(results['semantic'], target['label'])
+            sky_mask = torch.where(target['label'] == 4, 1., 0.)
+            d['sky_depth'] = self.lambda_sky * sky_mask * torch.exp(-results['depth'])
+
+        if kwargs.get('depth_mono', False):
+            depth_2d = target['depth'] / 25
+            mask = depth_2d > 0
+            weight = torch.where(mask, 1., 0.)
+            scale, shift = compute_scale_and_shift(results['depth'][mask].detach(), depth_2d[mask])
+            d['depth_mono'] = weight * self.lambda_depth_mono * \
+                torch.exp(-results['depth'].detach() / kwargs.get('scale', 1)) * \
+                (scale * results['depth'] + shift - depth_2d) ** 2
+        return d
+
+    def mask_regularize(self, mask, size_delta, digit_delta):
+        focus_epsilon = 0.02
+        loss_focus_size = torch.mean(torch.pow(mask, 2)) * size_delta
+        loss_focus_digit = torch.mean(1 / ((mask - 0.5) ** 2 + focus_epsilon)) * digit_delta
+        return loss_focus_size, loss_focus_digit

@@ -1,0 +1,175 @@
+"""render(model, rays_o, rays_d, **kwargs) — the L2 render API of the reference
+(models/rendering.py:13-251) on the MI355X operator surface.
+
+Train keys: deltas, ts, rays_a, total_samples, sigma, xyzs, vr_samples, opacity, depth, rgb,
+            normal_pred, semantic, ws, Ro, Rp                     (rendering.py:205-251)
+Test keys:  opacity, depth, rgb, normal_pred, normal_raw, semantic, total_samples, points, mask
+                                                                   (rendering.py:176-185)
+kwargs read: test_time, to_cpu, to_numpy, exp_step_factor, embedding_a, num_classes, max_samples,
+             T_threshold, use_skybox, random_bg (+ passed through to the model).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import vren
+from ._lib import call
+from .custom_functions import RayAABBIntersector, RayMarcher, RefLoss, VolumeRenderer
+
+MAX_SAMPLES = 1024
+NEAR_DISTANCE = 0.01
+
+
+def render(model, rays_o, rays_d, **kwargs):
+    rays_o = rays_o.contiguous()
+    rays_d = rays_d.contiguous()
+    _, hits_t, _ = RayAABBIntersector.apply(rays_o, rays_d, model.center, model.half_size, 1)
+    # 0 <= t1 < NEAR_DISTANCE -> NEAR_DISTANCE (rendering.py:30), one fused launch
+    call("clamp_near", hits_t, hits_t.shape[0], 1, NEAR_DISTANCE)
+
+    fn = _render_rays_test if kwargs.get('test_time', False) else _render_rays_train
+    results = fn(model, rays_o, rays_d, hits_t, **kwargs)
+    if kwargs.get('to_cpu', False):
+        for k, v in results.items():
+            v = v.cpu()
+            if kwargs.get('to_numpy', False):
+                v = v.numpy()
+            results[k] = v
+    return results
+
+
+def volume_render(model, rays_o, rays_d, hits_t, opacity, depth, rgb, normal_pred, normal_raw, sem, **kwargs):
+    """Progressive test-time marching (rendering.py:46-133): the per-ray accumulators are updated
+    in place; returns the total number of samples evaluated."""
+    N_rays = len(rays_o)
+    device = rays_o.device
+    exp_step_factor = kwargs.get('exp_step_factor', 0.)
+    classes = kwargs.get('num_classes', 7)
+    T_threshold = kwargs.get('T_threshold', 1e-4)
+    samples = 0
+    total_samples = 0
+    alive_indices = torch.arange(N_rays, device=device)
+    # synthetic scenes are mostly background: 1 sample per round retires those rays quickly
+    min_samples = 1 if exp_step_factor == 0 else 4
+
+    while samples < kwargs.get('max_samples', MAX_SAMPLES):
+        N_alive = len(alive_indices)
+        if N_alive == 0:
+            break
+        N_samples = max(min(N_rays // N_alive, 64), min_samples)
+        samples += N_samples
+
+        xyzs, dirs, deltas, ts, N_eff_samples = vren.raymarching_test(
+            rays_o, rays_d, hits_t, alive_indices, model.density_bitfield, model.cascades, model.scale,
+            exp_step_factor, model.grid_size, MAX_SAMPLES, N_samples)
+        total_samples += N_eff_samples.sum()
+        xyzs = xyzs.reshape(-1, 3)
+        dirs = dirs.reshape(-1, 3)
+        valid_mask = ~torch.all(dirs == 0, dim=1)
+        if valid_mask.sum() == 0:
+            break
+
+        n_pts = len(xyzs)
+        sigmas = torch.zeros(n_pts, device=device)
+        rgbs = torch.zeros(n_pts, 3, device=device)
+        normals_pred = torch.zeros(n_pts, 3, device=device)
+        normals_raw = torch.zeros(n_pts, 3, device=device)
+        sems = torch.zeros(n_pts, classes, device=device)
+
+        _sigmas, _rgbs, _normals_pred, _normals_raw, _sems = \
+            model.forward_test(xyzs[valid_mask], dirs[valid_mask], **kwargs)
+        sigmas[valid_mask] = _sigmas.detach().float()
+        rgbs[valid_mask] = _rgbs.detach().float()
+        normals_pred[valid_mask] = _normals_pred.float()
+        normals_raw[valid_mask] = _normals_raw.float()
+        sems[valid_mask] = _sems.float()
+
+        vren.composite_test_fw(
+            sigmas.view(N_alive, N_samples), rgbs.view(N_alive, N_samples, 3),
+            normals_pred.view(N_alive, N_samples, 3), normals_raw.view(N_alive, N_samples, 3),
+            sems.view(N_alive, N_samples, classes), deltas, ts, hits_t, alive_indices, T_threshold, classes,
+            N_eff_samples, opacity, depth, rgb, normal_pred, normal_raw, sem)
+        alive_indices = alive_indices[alive_indices >= 0]
+
+    if kwargs.get('use_skybox', False):
+        rgb_bg = model.forward_skybox(rays_d)
+    else:
+        rgb_bg = torch.zeros(3, device=device)
+    rgb += rgb_bg * (1 - opacity)[:, None]
+    return total_samples
+
+
+@torch.no_grad()
+def _render_rays_test(model, rays_o, rays_d, hits_t, **kwargs):
+    hits_t = hits_t[:, 0, :].contiguous()
+    classes = kwargs.get('num_classes', 7)
+    N_rays = len(rays_o)
+    device = rays_o.device
+    opacity = torch.zeros(N_rays, device=device)
+    depth = torch.zeros(N_rays, device=device)
+    rgb = torch.zeros(N_rays, 3, device=device)
+    normal_pred = torch.zeros(N_rays, 3, device=device)
+    normal_raw = torch.zeros(N_rays, 3, device=device)
+    sem = torch.zeros(N_rays, classes, device=device)
+    mask = torch.zeros(N_rays, device=device)
+
+    total_samples = volume_render(model, rays_o, rays_d, hits_t, opacity, depth, rgb, normal_pred, normal_raw, sem,
+                                  **kwargs)
+    results = {
+        'opacity': opacity, 'depth': depth, 'rgb': rgb,
+        'normal_pred': F.normalize(normal_pred, dim=-1),
+        'normal_raw': F.normalize(normal_raw, dim=-1),
+        'semantic': torch.argmax(sem, dim=-1, keepdim=True),
+        'total_samples': total_samples,
+        'points': rays_o + rays_d * depth.unsqueeze(-1),
+        'mask': mask,
+    }
+    return results
+
+
+def _render_rays_train(model, rays_o, rays_d, hits_t, **kwargs):
+    exp_step_factor = kwargs.get('exp_step_factor', 0.)
+    T_threshold = kwargs.get('T_threshold', 1e-4)
+    classes = kwargs.get('num_classes', 7)
+    results = {}
+    with torch.no_grad():
+        rays_a, xyzs, dirs, results['deltas'], results['ts'], total_samples = RayMarcher.apply(
+            rays_o, rays_d, hits_t[:, 0], model.density_bitfield, model.cascades, model.scale, exp_step_factor,
+            model.grid_size, MAX_SAMPLES)
+    results['rays_a'] = rays_a
+    results['total_samples'] = total_samples
+
+    # per-ray tensor kwargs (embedding_a, exposure, ...) are repeated per sample; like the
+    # reference this rewrites kwargs in place (rendering.py:217-219)
+    for k, v in kwargs.items():
+        if isinstance(v, torch.Tensor):
+            kwargs[k] = torch.repeat_interleave(v[rays_a[:, 0]], rays_a[:, 2], 0)
+    sigmas, rgbs, normals_raw, normals_pred, sems = model(xyzs, dirs, **kwargs)
+    results['sigma'] = sigmas
+    results['xyzs'] = xyzs
+
+    (results['vr_samples'], results['opacity'], results['depth'], results['rgb'], results['normal_pred'],
+     results['semantic'], results['ws']) = VolumeRenderer.apply(
+        sigmas.contiguous(), rgbs.contiguous(), normals_pred.contiguous(), sems.contiguous(),
+        results['deltas'], results['ts'], rays_a, T_threshold, classes)
+
+    if kwargs.get('use_skybox', False):
+        rgb_bg = model.forward_skybox(rays_d)
+    elif exp_step_factor != 0 and kwargs.get('random_bg', False):
+        rgb_bg = torch.rand(3, device=rays_o.device)
+    else:
+        rgb_bg = torch.zeros(3, device=rays_o.device)
+    results['rgb'] = results['rgb'] + rgb_bg * (1 - results['opacity'])[:, None]
+
+    # Ref-NeRF normal regularisers (rendering.py:243-249)
+    normals_diff = (normals_raw - normals_pred) ** 2
+    dirs_n = F.normalize(dirs, p=2, dim=-1, eps=1e-6)
+    normals_ori = torch.clamp(torch.sum(normals_raw * dirs_n, dim=-1), min=0.) ** 2
+    results['Ro'], results['Rp'] = RefLoss.apply(
+        sigmas.detach().contiguous(), normals_diff.contiguous(), normals_ori.contiguous(),
+        results['deltas'], results['ts'], rays_a, T_threshold)
+    return results
+
+
+# name-mangled aliases the reference module exposes internally
+__render_rays_train = _render_rays_train
+__render_rays_test = _render_rays_test

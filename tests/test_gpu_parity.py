@@ -1,0 +1,470 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the vren/tinycudann-shaped modules)
+against the CPU oracle on the same seeded inputs.  Run with `-m gpu` on an MI355X.
+
+Bars: bit-exact for integer/index work and for the fp32 marcher/intersector (same operation
+order, no FMA contraction on either side); stated tolerances for compositing (parallel scans,
+__expf), the hash grid (atomic summation order) and the MLP (MFMA accumulation order).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import borderline_rays, make_bitfield, make_rays, make_segments, rng
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def close(a, b, rtol, atol):
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
+
+
+# ---------------------------------------------------------------------------- R1 / O1
+@pytest.mark.parametrize("n_rays,n_vox,max_hits", [(0, 1, 1), (1, 1, 1), (1000, 1, 1), (513, 7, 3), (300, 20, 4)])
+def test_ray_aabb_intersect_bit_exact(ngp, n_rays, n_vox, max_hits):
+    g = rng(10)
+    o, d = make_rays(max(n_rays, 1), scale=1.0, seed=11)
+    o, d = o[:n_rays], d[:n_rays]
+    if n_rays > 10:
+        d[3, 0] = 0.0  # axis-parallel ray: 1/d = inf
+        d[4] = [0.0, 0.0, 1.0]
+    centers = ((g.random((n_vox, 3)) - 0.5) * (0.0 if n_vox == 1 else 1.5)).astype(np.float32)
+    half = (0.2 + 0.5 * g.random((n_vox, 3))).astype(np.float32)
+    cnt, t, idx = ngp.vren.ray_aabb_intersect(T(o), T(d), T(centers), T(half), max_hits)
+    ocnt, ot, oidx = oracle.ray_aabb_intersect(o, d, centers, half, max_hits)
+    assert np.array_equal(N(cnt), ocnt)
+    assert np.array_equal(N(t), ot, equal_nan=True)
+    assert np.array_equal(N(idx), oidx)
+
+
+def test_ray_sphere_intersect_bit_exact(ngp):
+    g = rng(12)
+    o, d = make_rays(777, scale=1.0, seed=13)
+    centers = ((g.random((9, 3)) - 0.5) * 1.5).astype(np.float32)
+    radii = (0.1 + 0.4 * g.random(9)).astype(np.float32)
+    cnt, t, idx = ngp.vren.ray_sphere_intersect(T(o), T(d), T(centers), T(radii), 4)
+    ocnt, ot, oidx = oracle.ray_sphere_intersect(o, d, centers, radii, 4)
+    assert np.array_equal(N(cnt), ocnt)
+    assert np.array_equal(N(t), ot, equal_nan=True)
+    assert np.array_equal(N(idx), oidx)
+
+
+def test_morton_roundtrip_and_oracle(ngp):
+    g = rng(14)
+    coords = g.integers(0, 128, (5000, 3)).astype(np.int32)
+    idx = ngp.vren.morton3D(T(coords))
+    assert np.array_equal(N(idx), oracle.morton3D(coords))
+    back = ngp.vren.morton3D_invert(idx)
+    assert np.array_equal(N(back), coords)
+    assert np.array_equal(N(back), oracle.morton3D_invert(N(idx)))
+    # full 128^3 grid is a permutation
+    gx = np.stack(np.meshgrid(*[np.arange(128)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    full = N(ngp.vren.morton3D(T(gx)))
+    assert np.array_equal(np.sort(full), np.arange(128 ** 3))
+
+
+def test_packbits_bit_exact(ngp):
+    g = rng(15)
+    grid = (g.random(2 * 64 ** 3) * 10 - 1).astype(np.float32)
+    grid[::7] = -1.0
+    out = torch.zeros(grid.size // 8, dtype=torch.uint8, device=DEV)
+    ngp.vren.packbits(T(grid), 4.5, out)
+    assert np.array_equal(N(out), oracle.packbits(grid, 4.5))
+
+
+# ---------------------------------------------------------------------------- R3 / T1
+MARCH_CASES = [
+    # cascades, scale, exp_step_factor, fill, n_rays, max_samples
+    (1, 0.5, 0.0, 0.05, 2048, 1024),
+    (1, 0.5, 0.0, 1.00, 257, 1024),     # warm-up: everything occupied, rays hit the 1024 cap region
+    (5, 8.0, 1 / 256, 0.03, 1500, 1024),
+    (6, 16.0, 1 / 256, 0.02, 700, 256),
+    (1, 0.5, 0.0, 0.0, 64, 1024),       # empty grid: no samples at all
+]
+
+
+def _march_inputs(cascades, scale, fill, n_rays, seed):
+    o, d = make_rays(n_rays, scale=min(scale, 2.0), seed=seed)
+    center = np.zeros((1, 3), np.float32)
+    half = np.full((1, 3), scale, np.float32)
+    _, hits_t, _ = oracle.ray_aabb_intersect(o, d, center, half, 1)
+    hits_t = hits_t[:, 0]
+    m = (hits_t[:, 0] >= 0) & (hits_t[:, 0] < 0.01)
+    hits_t[m, 0] = 0.01
+    bits = make_bitfield(cascades, 128, fill=fill, seed=seed + 1) if fill > 0 else np.zeros(cascades * 128 ** 3 // 8, np.uint8)
+    noise = rng(seed + 2).random(n_rays).astype(np.float32)
+    return o, d, np.ascontiguousarray(hits_t), bits, noise
+
+
+@pytest.mark.parametrize("case", MARCH_CASES)
+def test_raymarching_train_bit_exact(ngp, case):
+    cascades, scale, esf, fill, n_rays, max_samples = case
+    o, d, hits_t, bits, noise = _march_inputs(cascades, scale, fill, n_rays, seed=20)
+    ra, xyz, dirs, dl, ts, cnt = ngp.vren.raymarching_train(T(o), T(d), T(hits_t), T(bits), cascades, scale, esf,
+                                                            T(noise), 128, max_samples)
+    ora, oxyz, odirs, odl, ots, ocnt = oracle.raymarching_train(o, d, hits_t, bits, cascades, scale, esf, noise, 128,
+                                                               max_samples)
+    assert np.array_equal(N(cnt), ocnt)
+    n = int(ocnt[0])
+    if fill > 0 and n_rays > 100:
+        assert n > 0
+    assert np.array_equal(N(ra), ora)
+    assert np.array_equal(N(ts)[:n], ots[:n])
+    assert np.array_equal(N(dl)[:n], odl[:n])
+    assert np.array_equal(N(xyz)[:n], oxyz[:n])
+    assert np.array_equal(N(dirs)[:n], odirs[:n])
+    # drop-in contract: rows behind counter[0] are zero (reference allocates torch::zeros)
+    assert not N(ts)[n:].any() and not N(xyz)[n:].any()
+
+
+def test_raymarcher_function_trims_and_orders(ngp):
+    cascades, scale, esf = 1, 0.5, 0.0
+    o, d, hits_t, bits, _ = _march_inputs(cascades, scale, 0.05, 1000, seed=30)
+    torch.manual_seed(1)
+    ra, xyz, dirs, dl, ts, total = ngp.custom_functions.RayMarcher.apply(
+        T(o), T(d), T(hits_t), T(bits), cascades, scale, esf, 128, 1024)
+    n = int(total)
+    assert xyz.shape == (n, 3) and dirs.shape == (n, 3) and dl.shape == (n,) and ts.shape == (n,)
+    ra = N(ra)
+    assert np.array_equal(ra[:, 0], np.arange(1000))
+    assert np.array_equal(ra[:, 1], np.cumsum(ra[:, 2]) - ra[:, 2])
+    assert ra[:, 2].sum() == n
+    # samples of a ray are strictly increasing in t and spaced by delta
+    tsn, dln = N(ts), N(dl)
+    for r in range(0, 1000, 37):
+        s, c = ra[r, 1], ra[r, 2]
+        if c > 1:
+            assert np.all(np.diff(tsn[s:s + c]) >= dln[s:s + c - 1] * 0.999)
+
+
+@pytest.mark.parametrize("case", [(1, 0.5, 0.0, 0.05, 1500), (5, 8.0, 1 / 256, 0.03, 900)])
+def test_raymarching_test_bit_exact(ngp, case):
+    cascades, scale, esf, fill, n_rays = case
+    o, d, hits_t, bits, _ = _march_inputs(cascades, scale, fill, n_rays, seed=40)
+    alive = np.arange(n_rays, dtype=np.int64)[::2].copy()
+    hits_gpu = T(hits_t.copy())
+    hits_cpu = hits_t.copy()
+    for n_samples in (1, 4, 64):  # successive rounds resume from the mutated hits_t
+        out = ngp.vren.raymarching_test(T(o), T(d), hits_gpu, T(alive), T(bits), cascades, scale, esf, 128, 1024,
+                                        n_samples)
+        ref = oracle.raymarching_test(o, d, hits_cpu, alive, bits, cascades, scale, esf, 128, 1024, n_samples)
+        for a, b in zip(out, ref):
+            assert np.array_equal(N(a), b)
+        assert np.array_equal(N(hits_gpu), hits_cpu)
+
+
+# ---------------------------------------------------------------------------- V1 / V2 / V3 / D1
+def _composite_inputs(n_rays, max_len, classes, seed, sigma_scale=30.0):
+    g = rng(seed)
+    rays_a, n = make_segments(n_rays, max_len, seed=seed + 1)
+    # shuffle rows: the kernels must honour ray_idx, not the row number
+    perm = g.permutation(n_rays)
+    rays_a = rays_a[perm]
+    sig = (g.random(n) ** 3 * sigma_scale).astype(np.float32)
+    sig[g.random(n) < 0.3] = 0.0
+    deltas = (0.002 + 0.02 * g.random(n)).astype(np.float32)
+    ts = np.zeros(n, np.float32)
+    for _, s, c in rays_a:
+        ts[s:s + c] = 0.5 + np.cumsum(deltas[s:s + c])
+    rgbs = g.random((n, 3)).astype(np.float32)
+    nrm = g.normal(size=(n, 3)).astype(np.float32)
+    sems = g.random((n, classes)).astype(np.float32)
+    return rays_a, n, sig, deltas, ts, rgbs, nrm, sems
+
+
+@pytest.mark.parametrize("n_rays,max_len,classes,T_thr", [
+    (1, 1, 7, 1e-4), (700, 40, 7, 1e-4), (300, 700, 7, 1e-4), (200, 90, 0, 1e-2), (150, 64, 10, 0.0),
+    (64, 33, 40, 1e-4)])
+def test_composite_train_fw_bw(ngp, n_rays, max_len, classes, T_thr):
+    rays_a, n, sig, deltas, ts, rgbs, nrm, sems = _composite_inputs(n_rays, max_len, classes, seed=50 + max_len)
+    ok = ~borderline_rays(sig, deltas, rays_a, T_thr)
+    out = ngp.vren.composite_train_fw(T(sig), T(rgbs), T(nrm), T(sems), T(deltas), T(ts), T(rays_a), T_thr, classes)
+    ref = oracle.composite_train_fw(sig, rgbs, nrm, sems, deltas, ts, rays_a, T_thr, classes)
+    total, opacity, depth, rgb, normal, sem, ws = [N(x) for x in out]
+    ray_ok = np.zeros(n_rays, bool)
+    ray_ok[rays_a[ok, 0]] = True
+    assert np.array_equal(total[ray_ok], ref[0][ray_ok])
+    for a, b in zip((opacity, depth, rgb, normal, sem), ref[1:6]):
+        close(a[ray_ok], b[ray_ok], rtol=2e-5, atol=2e-6)
+    smask = np.zeros(n, bool)
+    for i, (_, s, c) in enumerate(rays_a):
+        smask[s:s + c] = ok[i]
+    close(ws[smask], ref[6][smask], rtol=2e-5, atol=1e-7)
+
+    # backward with random upstream gradients, fed the ORACLE forward outputs on both sides
+    g = rng(60)
+    dO, dD = g.normal(size=n_rays).astype(np.float32), g.normal(size=n_rays).astype(np.float32)
+    dRGB, dN = g.normal(size=(n_rays, 3)).astype(np.float32), g.normal(size=(n_rays, 3)).astype(np.float32)
+    dS, dws = g.normal(size=(n_rays, classes)).astype(np.float32), g.normal(size=n).astype(np.float32)
+    bw = ngp.vren.composite_train_bw(T(dO), T(dD), T(dRGB), T(dN), T(dS), T(dws), T(sig), T(rgbs), T(nrm),
+                                     T(ref[6]), T(deltas), T(ts), T(rays_a), T(ref[1]), T(ref[2]), T(ref[3]),
+                                     T(ref[4]), T_thr, classes)
+    rbw = oracle.composite_train_bw(dO, dD, dRGB, dN, dS, dws, sig, rgbs, nrm, ref[6], deltas, ts, rays_a, ref[1],
+                                    ref[2], ref[3], ref[4], T_thr, classes)
+    for a, b in zip(bw, rbw):
+        a = N(a)
+        # dL_dsigmas is a difference of O(1) running sums: absolute tolerance scaled by delta
+        close(a[smask], b[smask], rtol=2e-4, atol=2e-5)
+
+
+def test_composite_alpha_fw(ngp):
+    rays_a, n, sig, deltas, *_ = _composite_inputs(400, 50, 0, seed=70)
+    ok = ~borderline_rays(sig, deltas, rays_a, 1e-4)
+    a, w = ngp.vren.composite_alpha_fw(T(sig), T(deltas), T(rays_a), 1e-4)
+    ra, rw = oracle.composite_alpha_fw(sig, deltas, rays_a, 1e-4)
+    smask = np.zeros(n, bool)
+    for i, (_, s, c) in enumerate(rays_a):
+        smask[s:s + c] = ok[i]
+    close(N(a)[smask], ra[smask], 2e-5, 1e-7)
+    close(N(w)[smask], rw[smask], 2e-5, 1e-7)
+
+
+def test_refloss_fw_bw(ngp):
+    rays_a, n, sig, deltas, ts, rgbs, nrm, _ = _composite_inputs(500, 60, 0, seed=80)
+    ok = ~borderline_rays(sig, deltas, rays_a, 1e-4)
+    ndiff = (rgbs ** 2).astype(np.float32)
+    nori = np.abs(nrm[:, 0]).astype(np.float32)
+    lo, lp = ngp.vren.composite_refloss_fw(T(sig), T(ndiff), T(nori), T(deltas), T(ts), T(rays_a), 1e-4)
+    rlo, rlp = oracle.composite_refloss_fw(sig, ndiff, nori, deltas, ts, rays_a, 1e-4)
+    ray_ok = np.zeros(len(rays_a), bool)
+    ray_ok[rays_a[ok, 0]] = True
+    close(N(lo)[ray_ok], rlo[ray_ok], 2e-5, 2e-6)
+    close(N(lp)[ray_ok], rlp[ray_ok], 2e-5, 2e-6)
+    g = rng(81)
+    dlo, dlp = g.normal(size=len(rays_a)).astype(np.float32), g.normal(size=(len(rays_a), 3)).astype(np.float32)
+    bw = ngp.vren.composite_refloss_bw(T(dlo), T(dlp), T(sig), T(ndiff), T(nori), T(deltas), T(ts), T(rays_a),
+                                       T(rlo), T(rlp), 1e-4)
+    rbw = oracle.composite_refloss_bw(dlo, dlp, sig, ndiff, nori, deltas, ts, rays_a, rlo, rlp, 1e-4)
+    smask = np.zeros(n, bool)
+    for i, (_, s, c) in enumerate(rays_a):
+        smask[s:s + c] = ok[i]
+    for a, b in zip(bw, rbw):
+        close(N(a)[smask], b[smask], 2e-4, 2e-5)
+
+
+@pytest.mark.parametrize("n_rays,max_len", [(600, 40), (100, 900), (5, 1)])
+def test_distortion_loss_fw_bw(ngp, n_rays, max_len):
+    rays_a, n, sig, deltas, ts, *_ = _composite_inputs(n_rays, max_len, 0, seed=90 + max_len)
+    ws = oracle.composite_train_fw(sig, np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32),
+                                   np.zeros((n, 0), np.float32), deltas, ts, rays_a, 1e-4, 0)[6]
+    loss, wi, wti = ngp.vren.distortion_loss_fw(T(ws), T(deltas), T(ts), T(rays_a))
+    rl, rwi, rwti = oracle.distortion_loss_fw(ws, deltas, ts, rays_a)
+    close(N(wi), rwi, 1e-5, 1e-7)
+    close(N(wti), rwti, 1e-5, 1e-7)
+    # the loss is a cancellation of O(w*wt) products: absolute tolerance on that scale
+    close(N(loss), rl, 1e-3, 2e-6)
+    g = rng(91)
+    dl = g.normal(size=n_rays).astype(np.float32)
+    d = ngp.vren.distortion_loss_bw(T(dl), T(rwi), T(rwti), T(ws), T(deltas), T(ts), T(rays_a))
+    rd = oracle.distortion_loss_bw(dl, rwi, rwti, ws, deltas, ts, rays_a)
+    close(N(d), rd, 1e-5, 1e-6)
+
+
+def test_composite_test_fw(ngp):
+    g = rng(100)
+    n_rays, na, ns, C = 900, 500, 16, 7
+    alive = np.sort(g.choice(n_rays, na, replace=False)).astype(np.int64)
+    sig = (g.random((na, ns)) ** 2 * 40).astype(np.float32)
+    deltas = (0.002 + 0.01 * g.random((na, ns))).astype(np.float32)
+    ts = np.cumsum(deltas, 1).astype(np.float32)
+    rgbs, nrm, nraw = (g.random((na, ns, 3)).astype(np.float32) for _ in range(3))
+    sems = g.random((na, ns, C)).astype(np.float32)
+    n_eff = g.integers(0, ns + 1, na).astype(np.int32)
+    hits_t = np.zeros((n_rays, 2), np.float32)
+    state = [g.random(n_rays).astype(np.float32) * 0.5, g.random(n_rays).astype(np.float32),
+             g.random((n_rays, 3)).astype(np.float32), g.random((n_rays, 3)).astype(np.float32),
+             g.random((n_rays, 3)).astype(np.float32), g.random((n_rays, C)).astype(np.float32)]
+    gpu_state = [T(s.copy()) for s in state]
+    gpu_alive = T(alive.copy())
+    ngp.vren.composite_test_fw(T(sig), T(rgbs), T(nrm), T(nraw), T(sems), T(deltas), T(ts), T(hits_t), gpu_alive,
+                               1e-2, C, T(n_eff), *gpu_state)
+    cpu_alive = alive.copy()
+    oracle.composite_test_fw(sig, rgbs, nrm, nraw, sems, deltas, ts, hits_t, cpu_alive, 1e-2, C, n_eff, *state)
+    # alive flags may differ only for rays whose T lands within rounding of the threshold
+    agree = N(gpu_alive) == cpu_alive
+    assert agree.mean() > 0.995
+    for a, b in zip(gpu_state, state):
+        close(N(a), b, 2e-5, 2e-6)
+
+
+def test_segment_csr(ngp):
+    g = rng(110)
+    rays_a, n = make_segments(300, 50, seed=111)
+    src = g.normal(size=(n, 3)).astype(np.float32)
+    indptr = np.concatenate([rays_a[:, 1], rays_a[-1:, 1] + rays_a[-1:, 2]])
+    out = ngp.torch_scatter.segment_csr(T(src), T(indptr))
+    close(N(out), oracle.segment_csr_sum(src, indptr), 1e-5, 1e-6)
+
+
+# ---------------------------------------------------------------------------- H1-H5
+GRID_CASES = [
+    # L, F, log2_T, base, per_level_scale, n
+    (16, 8, 19, 16, 1.3195079, 3000),      # the reference's xyz_encoder at scale 0.5
+    (16, 8, 14, 16, 1.3195079, 2000),      # small table: heavy hash collisions
+    (8, 2, 16, 16, 2.0, 2500),             # implicit_mask.py configuration
+    (16, 2, 19, 16, 1.3819, 1500),
+    (4, 4, 12, 8, 1.5, 1000),
+    (3, 1, 10, 4, 2.0, 777),               # group of 3 lanes: serial input-grad fallback
+]
+
+
+@pytest.mark.parametrize("case", GRID_CASES)
+def test_grid_fwd_bwd(ngp, case):
+    L, Fd, log2T, base, pls, n = case
+    tcnn = ngp.tinycudann
+    enc = tcnn.Encoding(3, {"otype": "HashGrid", "n_levels": L, "n_features_per_level": Fd,
+                            "log2_hashmap_size": log2T, "base_resolution": base, "per_level_scale": pls}).to(DEV)
+    desc, n_params = oracle.grid_layout(L, Fd, log2T, base, pls)
+    assert n_params == enc.params.numel()
+    assert list(desc.offsets)[:L + 1] == list(enc.desc.offsets)[:L + 1]
+    g = rng(120 + L)
+    table = g.uniform(-1, 1, n_params).astype(np.float32)
+    x = g.random((n, 3)).astype(np.float32)
+    x[0] = [0.0, 0.0, 0.0]
+    x[1] = [1.0, 1.0, 1.0]      # the far corner (index wrap path)
+    x[2] = [0.5, 0.25, 0.75]    # lands exactly on cell boundaries at power-of-two resolutions
+    with torch.no_grad():
+        enc.params.copy_(T(table))
+    xt = T(x).requires_grad_(True)
+    y = enc(xt)
+    ry = oracle.grid_fwd(desc, table, x)
+    close(N(y), ry, 1e-5, 1e-6)
+
+    dy = g.normal(size=ry.shape).astype(np.float32)
+    dy[5:50] = 0.0              # zero-gradient samples (skipped by the scatter kernel)
+    gx, gp = torch.autograd.grad(y, [xt, enc.params], T(dy))
+    close(N(gx), oracle.grid_bwd_input(desc, table, x, dy), 2e-4, 2e-4)
+    rgp = oracle.grid_bwd_param(desc, x, dy, n_params)
+    # atomic accumulation order differs from the sequential oracle
+    close(N(gp), rgp, 1e-4, 1e-4 * max(1.0, np.abs(rgp).max() * 0.01))
+
+
+def test_grid_double_backward(ngp):
+    L, Fd, log2T, base, pls, n = 8, 8, 15, 16, 1.5, 600
+    tcnn = ngp.tinycudann
+    enc = tcnn.Encoding(3, {"otype": "HashGrid", "n_levels": L, "n_features_per_level": Fd,
+                            "log2_hashmap_size": log2T, "base_resolution": base, "per_level_scale": pls}).to(DEV)
+    desc, n_params = oracle.grid_layout(L, Fd, log2T, base, pls)
+    g = rng(130)
+    table = g.uniform(-1, 1, n_params).astype(np.float32)
+    x = g.random((n, 3)).astype(np.float32)
+    dy = g.normal(size=(n, L * Fd)).astype(np.float32)
+    v = g.normal(size=(n, 3)).astype(np.float32)
+    with torch.no_grad():
+        enc.params.copy_(T(table))
+    xt = T(x).requires_grad_(True)
+    dyt = T(dy).requires_grad_(True)
+    y = enc(xt)
+    (gx,) = torch.autograd.grad(y, xt, dyt, create_graph=True)
+    d_dy, d_p = torch.autograd.grad(gx, [dyt, enc.params], T(v))
+    rp, rdy = oracle.grid_bwd_bwd_input(desc, table, x, dy, v)
+    close(N(d_dy), rdy, 2e-4, 2e-4)
+    close(N(d_p), rp, 1e-4, 2e-4)
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3, 4])
+def test_sh(ngp, degree):
+    g = rng(140)
+    d = g.normal(size=(1000, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True) + 1) / 2
+    d = d.astype(np.float32)
+    enc = ngp.tinycudann.Encoding(3, {"otype": "SphericalHarmonics", "degree": degree}).to(DEV)
+    xt = T(d).requires_grad_(True)
+    y = enc(xt)
+    close(N(y), oracle.sh_fwd(d, degree), 1e-6, 1e-6)
+    # input gradient against central differences of the oracle (fp64 step on fp32 function)
+    dy = g.normal(size=(1000, degree * degree)).astype(np.float32)
+    (gx,) = torch.autograd.grad(y, xt, T(dy))
+    eps = 1e-3
+    fd = np.zeros((1000, 3))
+    for k in range(3):
+        dp, dm = d.copy(), d.copy()
+        dp[:, k] += eps
+        dm[:, k] -= eps
+        fd[:, k] = ((oracle.sh_fwd(dp, degree).astype(np.float64) - oracle.sh_fwd(dm, degree)) * dy).sum(1) / (2 * eps)
+    close(N(gx), fd, 2e-2, 2e-2)
+
+
+# ---------------------------------------------------------------------------- M1-M4
+@pytest.mark.parametrize("n,n_in,n_out,act,bias", [
+    (1000, 128, 128, "Softplus", True), (777, 144, 128, "ReLU", False), (513, 128, 32, "ReLU", False),
+    (300, 32, 16, "None", False), (1000, 128, 1, "Softplus", True), (129, 128, 16, "Sigmoid", False),
+    (64, 16, 64, "ReLU", False), (2000, 160, 128, "ReLU", False)])
+def test_linear_layers(ngp, n, n_in, n_out, act, bias):
+    g = rng(150 + n_in + n_out)
+    x = g.normal(size=(n, n_in)).astype(np.float32)
+    W = (g.normal(size=(n_out, n_in)) / np.sqrt(n_in)).astype(np.float32)
+    b = g.normal(size=n_out).astype(np.float32) if bias else None
+    code = oracle.ACT[act]
+    call = ngp._lib.call
+    y = torch.empty(n, n_out, device=DEV)
+    z = torch.empty(n, n_out, device=DEV)
+    call("linear_fwd", T(x), n_in, T(W), n_in, T(b) if bias else None, n, n_in, n_out, code, y, n_out, z)
+    ref = oracle.linear_fwd(x, W, b, act)
+    close(N(y), ref, 2e-5, 2e-5)
+    x64, W64 = x.astype(np.float64), W.astype(np.float64)
+    zref = x64 @ W64.T + (b if bias else 0)
+    close(N(z), zref, 2e-5, 2e-5)
+    dz = g.normal(size=(n, n_out)).astype(np.float32)
+    dx = torch.empty(n, n_in, device=DEV)
+    call("linear_bwd_input", T(dz), n_out, T(W), n_in, n, n_in, n_out, dx, n_in)
+    close(N(dx), dz.astype(np.float64) @ W64, 3e-5, 3e-5)
+    dW = torch.zeros(n_out, n_in, device=DEV)
+    db = torch.zeros(n_out, device=DEV)
+    call("linear_bwd_weight", T(dz), n_out, T(x), n_in, n, n_in, n_out, dW, n_in, db)
+    close(N(dW), dz.astype(np.float64).T @ x64, 1e-4, 1e-3)
+    close(N(db), dz.astype(np.float64).sum(0), 1e-4, 1e-3)
+
+
+def test_tcnn_network_matches_torch(ngp):
+    tcnn = ngp.tinycudann
+    net = tcnn.Network(144, 3, {"otype": "CutlassMLP", "activation": "ReLU", "output_activation": "Sigmoid",
+                                "n_neurons": 128, "n_hidden_layers": 1}).to(DEV)
+    assert net.params.numel() == 128 * 144 + 16 * 128   # 20,480
+    x = torch.randn(1500, 144, device=DEV, requires_grad=True)
+    y = net(x)
+    W1 = net.layer_weight(0).double()
+    W2 = net.layer_weight(1).double()
+    ref = torch.sigmoid(torch.relu(x.double() @ W1.T) @ W2.T)[:, :3]
+    close(N(y), N(ref), 2e-5, 2e-5)
+    g = torch.randn_like(y)
+    gx, gp = torch.autograd.grad(y, [x, net.params], g)
+    rx, rp = torch.autograd.grad(ref, [x, net.params], g.double())
+    close(N(gx), N(rx), 1e-4, 1e-4)
+    close(N(gp), N(rp), 1e-4, 1e-3)
+    # skybox-style network: 9 inputs padded to 16 with ones
+    sky = tcnn.Network(9, 3, {"otype": "CutlassMLP", "activation": "ReLU", "output_activation": "Sigmoid",
+                              "n_neurons": 32, "n_hidden_layers": 1}).to(DEV)
+    xs = torch.rand(100, 9, device=DEV)
+    xp = torch.cat([xs, torch.ones(100, 7, device=DEV)], 1).double()
+    refs = torch.sigmoid(torch.relu(xp @ sky.layer_weight(0).double().T) @ sky.layer_weight(1).double().T)[:, :3]
+    close(N(sky(xs)), N(refs), 2e-5, 2e-5)
+
+
+def test_adam_matches_torch(ngp):
+    n = 100003
+    torch.manual_seed(0)
+    p0 = torch.randn(n, device=DEV)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=1e-2, eps=1e-8)
+    p = p0.clone()
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for step in range(1, 6):
+        gr = torch.randn(n, device=DEV)
+        p_ref.grad = gr.clone()
+        opt.step()
+        gbuf = gr.clone()
+        ngp._lib.call("adam_step", p, gbuf, m, v, n, 1e-2, 0.9, 0.999, 1e-8, 0.0, step, None, 1)
+        assert not gbuf.any()
+    close(N(p), N(p_ref), 1e-5, 1e-6)
