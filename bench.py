@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the instant-NGP training hot path on MI355X.
+
+A "step" is one full training step of the reference's schedule (train.py:268-307 + optimizer):
+occupancy-grid update every 16 steps, ray/AABB + marcher, hash-grid + MLP field with analytic
+normals, compositing, NeRFLoss (rgb + opacity + distortion), backward, gradient all-reduce
+(N > 1), clip-by-norm + Adam.  Workload = BASELINE.json configs[1]: lego-like scene (synthetic
+"S-lego-proxy", no dataset offline), 800x800 images, 8192 rays per batch PER GPU, L=16 F=8 hash
+grids with T=2^19 (density) / 2^21 (colour), fp32.  Data parallel = weak scaling (each rank draws
+its own 8192 rays).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP-event timed inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle's noCUDA
+render path on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_SAMPLE = {        # SURVEY.md §8(d), fp32, L=16, F=8 (per encoder, per sample)
+    "grid_fwd": 4096 + 512,         # 8 corners x 16 levels x 32 B gathered + 512 B written
+    "grid_bwd_param": 4096 + 512,   # 4096 B of atomic adds + 512 B of dL_dy read
+    "grid_bwd_input": 4096 + 512 + 12,
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--rays", type=int, default=8192, help="rays per batch per GPU")
+    ap.add_argument("--from-scratch", action="store_true",
+                    help="start from an all-occupied grid (the reference's first 256 steps) instead of the "
+                         "steady-state occupancy of the analytic scene")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--cpu-samples", type=int, default=64)
+    return ap.parse_args()
+
+
+def cpu_baseline(model, scene, n_rays, n_samples):
+    """Times the CPU oracle's restatement of rendering_noCUDA.render (forward rendering of n_rays
+    rays x n_samples dense samples through the CPU hash-grid + MLP field) on the host cores."""
+    import oracle
+    from oracle import nocuda
+    from oracle.field import CpuNGP
+    state = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()
+             if k.endswith("params") or k.startswith("xyz_net")}
+    field = CpuNGP(state, scale=model.scale)
+    g = torch.Generator(device=scene.device).manual_seed(7)
+    img, pix = scene.sample_batch(n_rays, generator=g)
+    o, d = scene.rays(img, pix)
+    o, d = o.cpu().numpy(), d.cpu().numpy()
+    nocuda.render([field, field], o, d, [n_samples])  # warm-up (page-in, OpenMP pool)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        nocuda.render([field, field], o, d, [n_samples])
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 50:
+            break
+    return {
+        "value": n_rays * reps / el, "unit": "rays/s", "cores": oracle.num_threads(), "kind": "port",
+        "samples_per_s": n_rays * n_samples * reps / el,
+        "sample": f"{reps}x forward render of {n_rays} rays x {n_samples} dense samples "
+                  f"(oracle restatement of rendering_noCUDA.render + CPU hash-grid/MLP field, {el:.1f}s)",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import ngp_amd
+    from ngp_amd import _lib
+    from ngp_amd.networks import NGP
+    from ngp_amd.synthetic import LegoProxy
+    from ngp_amd.trainer import NGPTrainer, shard_seed
+    from ngp_amd.metrics import psnr
+
+    seed = 20220806
+    torch.manual_seed(seed)  # identical initial weights on every rank
+    np.random.seed(seed)
+    model = NGP(scale=0.5).to(dev)
+    G = model.grid_size
+    model.register_buffer("density_grid", torch.zeros(model.cascades, G ** 3, device=dev))
+    coords = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=dev)] * 3, indexing="ij"), -1)
+    model.register_buffer("grid_coords", coords.reshape(-1, 3).contiguous())
+    model.grid_rng = torch.Generator(device=dev).manual_seed(seed)  # same grid updates on all ranks
+
+    scene = LegoProxy(n_images=100, img_wh=(800, 800), device=dev, seed=seed)
+    trainer = NGPTrainer(model, lr=1e-2, num_epochs=20, steps_per_epoch=1000, exp_step_factor=0.0)
+    if not args.from_scratch:
+        model.density_grid.copy_(scene.occupancy_from_analytic(model))
+        ngp_amd.vren.packbits(model.density_grid.view(-1), 0.5, model.density_bitfield)
+        trainer.global_step = 1024  # past the all-cells warm-up; grid keeps updating every 16 steps
+        trainer.warmup_steps = 0
+    trainer.broadcast_state(0)
+
+    ray_gen = torch.Generator(device=dev).manual_seed(shard_seed(seed, rank))
+
+    def next_batch():
+        img, pix = scene.sample_batch(args.rays, generator=ray_gen)
+        o, d = scene.rays(img, pix)
+        gt, _ = scene.ground_truth(o, d, n_quad=256)
+        return o, d, gt
+
+    batches = [next_batch() for _ in range(min(args.warmup + args.steps, 64))]
+
+    def run(k, i0):
+        tot_samples = torch.zeros((), dtype=torch.int64, device=dev)
+        last = None
+        for i in range(k):
+            o, d, gt = batches[(i0 + i) % len(batches)]
+            loss, res = trainer.step(o, d, gt)
+            tot_samples += res["total_samples"]
+            last = (loss, res, gt)
+        return tot_samples, last
+
+    run(args.warmup, 0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    _lib.PROFILE = {k: [] for k in ("grid_fwd", "grid_bwd_param", "grid_bwd_input", "adam_step")}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tot_samples, last = run(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof, _lib.PROFILE = _lib.PROFILE, None
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    s = tot_samples.clone()
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_samples = int(s.item())
+
+    if rank == 0:
+        loss, res, gt = last
+        rays_total = args.rays * world * args.steps
+        # per-kernel device time over the timed region (HIP events on the launch stream)
+        kern = {}
+        for name, evs in prof.items():
+            if not evs:
+                continue
+            ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
+            if name.startswith("grid"):
+                # samples processed by each launch = the int64 `n` argument
+                ns = [a[0] for _, _, a in evs]
+                gbs = [BYTES_PER_SAMPLE[name] * n / (m * 1e-3) / 1e9 for n, m in zip(ns, ms) if m > 0]
+                kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
+                              "avg_samples": sum(ns) / len(ns), "GBps": sum(gbs) / max(len(gbs), 1)}
+            else:
+                kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms)}
+        grid_names = [k for k in kern if k.startswith("grid")]
+        dom = max(grid_names, key=lambda k: kern[k]["total_ms"])
+        roofline = {
+            "kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_ms": kern[dom]["avg_ms"], "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE[dom],
+            "note": "fp32 global atomics are bounded by ~1.3 TB/s of added bytes on MI355X "
+                    "(MI355X_MICROARCH.md), below the 8 TB/s HBM peak used for frac" if dom == "grid_bwd_param" else "",
+        }
+        out = {
+            "metric": "train rays/sec", "value": rays_total / elapsed, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "samples_per_s": total_samples / elapsed,
+            "samples_per_ray": total_samples / rays_total,
+            "train_psnr_last_batch": float(psnr(res["rgb"].detach(), gt)),
+            "loss": float(loss),
+            "config": {"workload": "NeRF-Synthetic-lego-like (S-lego-proxy analytic scene), 800x800, "
+                                   f"{args.rays} rays/batch/GPU, L=16 F=8 hashgrid T=2^19 (sigma) + 2^21 (rgb), fp32, "
+                                   "full train step incl. density-grid update/16 steps, NeRFLoss, clip+Adam",
+                       "rays_per_gpu": args.rays, "global_rays": args.rays * world,
+                       "occupancy": "all-occupied warm-up" if args.from_scratch else "steady state (analytic)",
+                       "parallelism": f"ray-batch dp{world}"},
+            "roofline": roofline,
+            "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, scene, args.cpu_rays, args.cpu_samples)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

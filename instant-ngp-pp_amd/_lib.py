@@ -92,10 +92,24 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-entry-point device timing: {name: [(start_event, end_event, tag), ...]}.  bench.py sets
+# this to bracket the kernels of the timed region with HIP events on the launch stream.
+PROFILE = None
+
+
 def call(name, *args):
     """Calls ngp_<name>(*args, current HIP stream).  Tensors are passed as device pointers."""
     lib = load()
-    rc = getattr(lib, "ngp_" + name)(*[_arg(a) for a in args], stream_ptr())
+    prof = PROFILE
+    if prof is not None and name in prof:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, "ngp_" + name)(*[_arg(a) for a in args], stream_ptr())
+        e1.record()
+        prof[name].append((e0, e1, tuple(a for a in args if isinstance(a, int))))
+    else:
+        rc = getattr(lib, "ngp_" + name)(*[_arg(a) for a in args], stream_ptr())
     if rc != 0:
         raise RuntimeError(f"ngp_{name} failed with code {rc}")
 

@@ -248,11 +248,13 @@ class NGP(nn.Module):
     def sample_uniform_and_occupied_cells(self, M, density_threshold):
         cells = []
         for c in range(self.cascades):
-            coords1 = torch.randint(self.grid_size, (M, 3), dtype=torch.int32, device=self.density_grid.device)
+            gen = getattr(self, 'grid_rng', None)  # shared-seed generator keeps DDP ranks' grids identical
+            coords1 = torch.randint(self.grid_size, (M, 3), dtype=torch.int32, device=self.density_grid.device,
+                                    generator=gen)
             indices1 = vren.morton3D(coords1).long()
             indices2 = torch.nonzero(self.density_grid[c] > density_threshold)[:, 0]
             if len(indices2) > 0:
-                rand_idx = torch.randint(len(indices2), (M,), device=self.density_grid.device)
+                rand_idx = torch.randint(len(indices2), (M,), device=self.density_grid.device, generator=gen)
                 indices2 = indices2[rand_idx]
             coords2 = vren.morton3D_invert(indices2.int())
             cells += [(torch.cat([indices1, indices2]), torch.cat([coords1, coords2]))]
@@ -294,7 +296,8 @@ class NGP(nn.Module):
         for c in range(self.cascades):
             indices, coords = cells[c]
             s = min(2 ** (c - 1), self.scale)
-            noise = torch.rand(coords.shape[0], 3, dtype=_f32, device=coords.device)
+            noise = torch.rand(coords.shape[0], 3, dtype=_f32, device=coords.device,
+                               generator=getattr(self, 'grid_rng', None))
             xyzs_w = torch.empty(coords.shape[0], 3, dtype=_f32, device=coords.device)
             call("grid_cell_points", coords.contiguous(), noise, coords.shape[0], self.grid_size, float(s), xyzs_w)
             density_grid_tmp[c, indices] = self.density(xyzs_w)

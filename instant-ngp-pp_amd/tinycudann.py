@@ -46,8 +46,16 @@ class _GridFwd(Function):
         if ctx.needs_input_grad[0]:
             dx = _GridBwdInput.apply(dy, x, params, enc)
         if ctx.needs_input_grad[1]:
-            dparams = torch.zeros_like(params)
-            call("grid_bwd_param", enc.desc, x, dy, x.shape[0], dparams)
+            buf = getattr(enc, "grad_buffer", None)
+            if buf is not None:
+                # trainer-owned flat gradient: scatter-add straight into it (autograd sees None)
+                call("grid_bwd_param", enc.desc, x, dy, x.shape[0], buf)
+            else:
+                dparams = torch.zeros_like(params)
+                call("grid_bwd_param", enc.desc, x, dy, x.shape[0], dparams)
+            cb = getattr(enc, "on_grad_ready", None)
+            if cb is not None:
+                cb()
         return dx, dparams, None
 
 

@@ -1,0 +1,164 @@
+"""Training schedule of the reference's NeRFSystem (train.py:82-345) without Lightning:
+
+  every 16 steps update_density_grid(0.01*1024/sqrt(3), warmup = step < 256)   train.py:272-275
+  render() -> NeRFLoss -> sum of term means -> backward                        train.py:279-307
+  gradient clipping by global norm 50, Adam(lr, eps=1e-8)                      train.py:244,435
+  CosineAnnealingLR over the epochs down to lr/30, stepped once per epoch      train.py:249-251
+  ray-batch data parallel: every rank draws its own rays, gradients are averaged  train.py:430-432
+
+MI355X-specific structure:
+  * all parameters live in ONE flat fp32 buffer (rgb table | xyz table | MLPs) with matching flat
+    gradient / Adam-state buffers: one fused Adam launch per step (which also applies the clip
+    coefficient and zeroes the gradient), two large RCCL all-reduces instead of per-tensor ones;
+  * the hash-grid scatter kernels accumulate straight into the flat gradient buffer (no
+    zeros_like + add pass over 800 MB);
+  * with world_size > 1 the rgb-table bucket (77 % of the bytes) is all-reduced on RCCL's stream
+    as soon as its scatter-add is enqueued, overlapping the density-path backward; the second
+    bucket overlaps the host-side work of the next step.  The clip norm needs every reduced
+    gradient, so the Adam launch waits for both.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from ._lib import call
+from .losses import NeRFLoss
+from .rendering import MAX_SAMPLES, render
+
+_f32 = torch.float32
+
+
+class GradBuckets:
+    """Sum-all-reduce of contiguous slices of one flat gradient buffer (device agnostic: the
+    gloo CPU tests drive this class directly)."""
+
+    def __init__(self, flat_grad, boundaries, group=None):
+        self.flat = flat_grad
+        self.bounds = list(boundaries)  # [0, b1, ..., n]
+        self.group = group
+        self.works = []
+
+    @property
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def reduce_bucket(self, i):
+        if self.world == 1:
+            return
+        lo, hi = self.bounds[i], self.bounds[i + 1]
+        self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+def shard_seed(base_seed, rank):
+    """per-rank decorrelated ray sampling (the reference leaves this to
+    DataLoader worker seeding)"""
+    return int(base_seed) + int(rank)
+
+
+class NGPTrainer:
+    def __init__(self, model, lr=1e-2, num_epochs=20, steps_per_epoch=1000, clip_norm=50.0,
+                 exp_step_factor=0.0, num_classes=7, density_threshold=0.01, render_kwargs=None, group=None):
+        self.model = model
+        self.base_lr = lr
+        self.num_epochs = num_epochs
+        self.steps_per_epoch = steps_per_epoch
+        self.clip_norm = clip_norm
+        self.exp_step_factor = exp_step_factor
+        self.num_classes = num_classes
+        self.density_threshold = density_threshold
+        self.render_kwargs = dict(render_kwargs or {})
+        self.loss_fn = NeRFLoss()
+        self.warmup_steps = 256
+        self.update_interval = 16
+        self.global_step = 0
+        self.group = group
+        self._flatten()
+
+    # ------------------------------------------------------------------ flat parameter store
+    def _flatten(self):
+        named = [(n, p) for n, p in self.model.named_parameters() if p.numel() > 0]
+        order = {"rgb_encoder.params": 0, "xyz_encoder.params": 1}
+        named.sort(key=lambda np_: order.get(np_[0], 2))
+        self.names = [n for n, _ in named]
+        sizes = [(p.numel() + 3) // 4 * 4 for _, p in named]  # keep every slice 16-byte aligned
+        total = sum(sizes)
+        dev = named[0][1].device
+        self.flat_param = torch.zeros(total, dtype=_f32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=_f32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=_f32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=_f32, device=dev)
+        self.scalars = torch.zeros(2, dtype=_f32, device=dev)  # [sum of squares, clip coefficient]
+        off = 0
+        self.slices = {}
+        for (n, p), sz in zip(named, sizes):
+            view = self.flat_param[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            self.slices[n] = (off, p.numel())
+            off += sz
+        # bucket 0 = rgb table, bucket 1 = everything else
+        b0 = self.slices["rgb_encoder.params"][1] if "rgb_encoder.params" in self.slices else 0
+        b0 = (b0 + 3) // 4 * 4
+        self.buckets = GradBuckets(self.flat_grad, [0, b0, total], group=self.group)
+        # scatter kernels accumulate directly into the flat gradient (see tinycudann._GridFwd)
+        for enc_name in ("rgb_encoder", "xyz_encoder"):
+            enc = getattr(self.model, enc_name, None)
+            if enc is not None:
+                enc.grad_buffer = enc.params.grad
+        if hasattr(self.model, "rgb_encoder"):
+            self.model.rgb_encoder.on_grad_ready = lambda: self.buckets.reduce_bucket(0)
+
+    # ------------------------------------------------------------------ schedule
+    def lr_at(self, epoch):
+        eta_min = self.base_lr / 30
+        return eta_min + (self.base_lr - eta_min) * (1 + math.cos(math.pi * epoch / self.num_epochs)) / 2
+
+    @property
+    def lr(self):
+        return self.lr_at(min(self.global_step // self.steps_per_epoch, self.num_epochs))
+
+    def step(self, rays_o, rays_d, rgb_gt):
+        """one training step on this rank's ray batch; returns (loss tensor, results dict)"""
+        model = self.model
+        if self.global_step % self.update_interval == 0:
+            model.update_density_grid(self.density_threshold * MAX_SAMPLES / 3 ** 0.5,
+                                      warmup=self.global_step < self.warmup_steps)
+        results = render(model, rays_o, rays_d, exp_step_factor=self.exp_step_factor,
+                         num_classes=self.num_classes, **self.render_kwargs)
+        loss_d = self.loss_fn(results, {"rgb": rgb_gt})
+        loss = sum(lo.mean() for lo in loss_d.values())
+        loss.backward()
+        self.optimizer_step()
+        return loss.detach(), results
+
+    def optimizer_step(self):
+        world = self.buckets.world
+        self.buckets.reduce_bucket(1)
+        self.buckets.wait()
+        n = self.flat_grad.numel()
+        self.scalars.zero_()
+        call("sumsq", self.flat_grad, n, self.scalars[0:1])
+        call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0 / world, self.scalars[1:2])
+        self.global_step += 1
+        # lr of the epoch this step belongs to (the scheduler ticks at epoch boundaries)
+        lr = self.lr_at(min((self.global_step - 1) // self.steps_per_epoch, self.num_epochs))
+        call("adam_step", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, n, float(lr), 0.9, 0.999,
+             1e-8, 0.0, self.global_step, self.scalars[1:2], 1)
+
+    # ------------------------------------------------------------------ multi-GPU helpers
+    def broadcast_state(self, src=0):
+        """start every rank from rank `src`'s parameters and occupancy grid (DDP does this at
+        construction and re-broadcasts buffers every forward; train.py:431)"""
+        if self.buckets.world == 1:
+            return
+        dist.broadcast(self.flat_param, src, group=self.group)
+        for name in ("density_grid", "density_bitfield"):
+            if hasattr(self.model, name):
+                dist.broadcast(getattr(self.model, name), src, group=self.group)

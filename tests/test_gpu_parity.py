@@ -343,7 +343,9 @@ def test_grid_fwd_bwd(ngp, case):
     dy = g.normal(size=ry.shape).astype(np.float32)
     dy[5:50] = 0.0              # zero-gradient samples (skipped by the scatter kernel)
     gx, gp = torch.autograd.grad(y, [xt, enc.params], T(dy))
-    close(N(gx), oracle.grid_bwd_input(desc, table, x, dy), 2e-4, 2e-4)
+    rgx = oracle.grid_bwd_input(desc, table, x, dy)
+    # sums of ~L*F*8 terms of size scale*|dy|*|table|: tolerance relative to that magnitude
+    close(N(gx), rgx, 2e-4, 3e-6 * np.abs(rgx).max())
     rgp = oracle.grid_bwd_param(desc, x, dy, n_params)
     # atomic accumulation order differs from the sequential oracle
     close(N(gp), rgp, 1e-4, 1e-4 * max(1.0, np.abs(rgp).max() * 0.01))
@@ -368,8 +370,8 @@ def test_grid_double_backward(ngp):
     (gx,) = torch.autograd.grad(y, xt, dyt, create_graph=True)
     d_dy, d_p = torch.autograd.grad(gx, [dyt, enc.params], T(v))
     rp, rdy = oracle.grid_bwd_bwd_input(desc, table, x, dy, v)
-    close(N(d_dy), rdy, 2e-4, 2e-4)
-    close(N(d_p), rp, 1e-4, 2e-4)
+    close(N(d_dy), rdy, 2e-4, 3e-6 * np.abs(rdy).max())
+    close(N(d_p), rp, 1e-4, 3e-6 * np.abs(rp).max() + 2e-4)
 
 
 @pytest.mark.parametrize("degree", [1, 2, 3, 4])
