@@ -1,7 +1,7 @@
 """Import alias: the product package lives in `instant-ngp-pp_amd/` (a directory name Python
 cannot spell in an `import` statement), so `import ngp_amd` loads it through importlib and
-re-exports it.  `ngp_amd.vren`, `ngp_amd.tinycudann`, `ngp_amd.rendering`, ... are the
-sub-modules."""
+registers the package and every sub-module under the `ngp_amd.*` names as well (the SAME module
+objects, so there is exactly one copy of each module and of the loaded libngp_hip.so)."""
 import importlib
 import os
 import sys
@@ -10,5 +10,9 @@ _ROOT = os.path.dirname(os.path.abspath(__file__))
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
-_pkg = importlib.import_module("instant-ngp-pp_amd")
+_REAL = "instant-ngp-pp_amd"
+_pkg = importlib.import_module(_REAL)
 sys.modules[__name__] = _pkg
+for _sub in ("_lib", "build", "vren", "tinycudann", "torch_scatter", "custom_functions", "rendering", "networks",
+             "losses", "metrics", "synthetic", "trainer"):
+    sys.modules[f"{__name__}.{_sub}"] = importlib.import_module(f"{_REAL}.{_sub}")
