@@ -34,6 +34,9 @@ BYTES_PER_SAMPLE = {        # SURVEY.md §8(d), fp32, L=16, F=8 (per encoder, pe
 }
 
 
+N_ARG = {"grid_fwd": 0, "grid_bwd_param": 1, "grid_bwd_input": 1}  # position of `n` among the int arguments
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,7 +172,7 @@ def main():
             ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
             if name.startswith("grid"):
                 # samples processed by each launch = the int64 `n` argument
-                ns = [a[0] for _, _, a in evs]
+                ns = [a[N_ARG[name]] for _, _, a in evs]
                 gbs = [BYTES_PER_SAMPLE[name] * n / (m * 1e-3) / 1e9 for n, m in zip(ns, ms) if m > 0]
                 kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
                               "avg_samples": sum(ns) / len(ns), "GBps": sum(gbs) / max(len(gbs), 1)}

@@ -221,30 +221,32 @@ typedef struct ngp_grid_desc {
 int64_t ngp_grid_layout(int n_levels, int n_features, int log2_hashmap_size,
                         int base_resolution, double per_level_scale, ngp_grid_desc* desc);
 
-/* y (n, L*F) = encode(x (n,3)); */
+/* y (n, L*F) = encode(x (n,3)); ldy / lddy = row stride in floats of y / dL_dy (>= L*F), so the
+ * encoder can write into (and its backward read from) a column block of a wider matrix such as
+ * rgb_net's [SH | grid features | appearance code] input (networks.py:229-231) with no concat. */
 int ngp_grid_fwd(const ngp_grid_desc* desc /* host */, const float* table, const float* x,
-                 int64_t n, float* y, void* stream);
+                 int64_t n, float* y, int64_t ldy, void* stream);
 
 /* dtable[(off+idx)*F+f] += w * dL_dy  (atomic fp32 scatter-add; caller zeroes dtable) */
-int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* dL_dy,
+int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* dL_dy, int64_t lddy,
                        int64_t n, float* dtable, void* stream);
 
 /* dL_dx (n,3) = sum_l d enc_l / dx . dL_dy_l */
 int ngp_grid_bwd_input(const ngp_grid_desc* desc, const float* table, const float* x,
-                       const float* dL_dy, int64_t n, float* dL_dx, void* stream);
+                       const float* dL_dy, int64_t lddy, int64_t n, float* dL_dx, void* stream);
 
 /* double backward of ngp_grid_bwd_input: given dL_ddLdx (n,3) (gradient flowing into
  * dL_dx), accumulates dtable (atomic) and writes dL_ddLdy (n, L*F).  Either output
  * may be NULL. */
 int ngp_grid_bwd_bwd_input(const ngp_grid_desc* desc, const float* table, const float* x,
-                           const float* dL_dy, const float* dL_ddLdx, int64_t n,
+                           const float* dL_dy, int64_t lddy, const float* dL_ddLdx, int64_t n,
                            float* dtable, float* dL_ddLdy, void* stream);
 
 /* ------------------------------------------------------------------------
  * H5  spherical harmonics (tcnn.Encoding otype SphericalHarmonics, degree 1..4,
  * networks.py:78-85,128-135).  x (n,3) in [0,1] -> y (n, degree^2).
  * ---------------------------------------------------------------------- */
-int ngp_sh_fwd(const float* x, int64_t n, int degree, float* y, void* stream);
+int ngp_sh_fwd(const float* x, int64_t n, int degree, float* y, int64_t ldy, void* stream);
 int ngp_sh_bwd_input(const float* x, const float* dL_dy, int64_t n, int degree,
                      float* dL_dx, void* stream);
 
@@ -257,8 +259,11 @@ int ngp_sh_bwd_input(const float* x, const float* dL_dy, int64_t n, int degree,
  * ngp_linear_bwd_input : dx (n, n_in) = dz (n, n_out) . W
  * ngp_linear_bwd_weight: dW (n_out, n_in) += dz^T . x ; db (n_out) += sum dz
  *                        (atomic split-K over samples; caller zeroes dW/db)
- * ngp_act_bwd : dz = dy * act'(.)  given the layer OUTPUT y (post-activation)
- *               for ReLU/Sigmoid/Exp, or the pre-activation for Softplus.
+ * ngp_act_bwd : dz = dy * act'(.) expressed through the layer OUTPUT y (post-activation):
+ *               ReLU y>0, Sigmoid y(1-y), Exp y, Softplus 1-exp(-y) (= sigmoid of the input).
+ * ngp_mlp_hidden_bwd : hidden-layer backward of a 2-layer MLP with a narrow output (n_out<=16,
+ *               H in {32,64,128}): dz2 = dOut*act2'(out) (optional output), dz1 = (dz2.W2)*act1'(hidden);
+ *               dOut == NULL means all ones (analytic d(sigma)/dx of the density head).
  * ldx/ldy/lddz/lddx/ldw are row strides in floats (>= the logical width); a W sub-block
  * (e.g. the columns of rgb_net's first layer that see the grid features) is addressed by
  * offsetting W and keeping ldw.
@@ -269,14 +274,20 @@ int ngp_linear_fwd(const float* x, int64_t ldx, const float* W, int64_t ldw, con
                    void* stream);
 
 int ngp_linear_bwd_input(const float* dz, int64_t lddz, const float* W, int64_t ldw,
-                         int64_t n, int n_in, int n_out, float* dx, int64_t lddx, void* stream);
+                         int64_t n, int n_in, int n_out, float* dx, int64_t lddx,
+                         int accumulate /* dx += instead of dx = */, void* stream);
 
 int ngp_linear_bwd_weight(const float* dz, int64_t lddz, const float* x, int64_t ldx,
                           int64_t n, int n_in, int n_out, float* dW, int64_t ldw,
                           float* db /* may be NULL */, void* stream);
 
-int ngp_act_bwd(const float* dy, const float* y_or_z, int64_t count, int activation,
+int ngp_act_bwd(const float* dy, const float* y, int64_t count, int activation,
                 float* dz, void* stream);
+
+int ngp_mlp_hidden_bwd(const float* dOut, int64_t lddo, const float* out, int64_t ldo, int act2,
+                       const float* W2, int64_t ldw2, const float* hidden, int64_t ldh, int act1,
+                       int64_t n, int H, int n_out, float* dz2, int64_t lddz2,
+                       float* dz1, int64_t lddz1, void* stream);
 
 /* ------------------------------------------------------------------------
  * fused Adam step (torch.optim.Adam(eps=1e-8) semantics, train.py:244) over one

@@ -14,6 +14,7 @@
 //     Lanes whose upstream gradient is exactly zero (samples behind the early-termination
 //     point, volumerendering.cu:111) issue no atomics.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -100,7 +101,7 @@ template <> __device__ __forceinline__ float vec_dot<4>(const float (&g)[4], con
 template <int F>
 __global__ void __launch_bounds__(256) grid_fwd_kernel(GridMeta meta, const float* __restrict__ table,
                                                        const float* __restrict__ x, int64_t n_items,
-                                                       float* __restrict__ y)
+                                                       float* __restrict__ y, int64_t ldy)
 {
     constexpr int V = F >= 4 ? 4 : F;   // floats per lane
     constexpr int LPI = F / V;          // lanes per item
@@ -136,24 +137,24 @@ __global__ void __launch_bounds__(256) grid_fwd_kernel(GridMeta meta, const floa
     float* o = reinterpret_cast<float*>(&out);
 #pragma unroll
     for (int j = 0; j < V; j++) o[j] = acc[j];
-    *reinterpret_cast<vec_t*>(y + item * F + sub * V) = out;
+    *reinterpret_cast<vec_t*>(y + sample * ldy + level * F + sub * V) = out;
 }
 
 // ------------------------------------------------------------------ param gradient (H2)
 template <int F>
 __global__ void __launch_bounds__(256) grid_bwd_param_kernel(GridMeta meta, const float* __restrict__ x,
-                                                             const float* __restrict__ dL_dy, int64_t n_items,
-                                                             float* __restrict__ dtable)
+                                                             const float* __restrict__ dL_dy, int64_t lddy,
+                                                             int64_t n_items, float* __restrict__ dtable)
 {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t item = tid / F;
     const int f = (int)(tid % F);
     if (item >= n_items) return;
-    const float g = dL_dy[item * F + f];
-    if (g == 0.0f) return; // adds nothing: skip the 8 atomics
     const uint32_t L = meta.n_levels;
     const int64_t sample = item / L;
     const uint32_t level = (uint32_t)(item - sample * L);
+    const float g = dL_dy[sample * lddy + level * F + f];
+    if (g == 0.0f) return; // adds nothing: skip the 8 atomics
     const LevelInfo li = level_info(meta, level);
     const Cell c = cell_of(x, sample, li.scale);
 #pragma unroll
@@ -165,14 +166,91 @@ __global__ void __launch_bounds__(256) grid_bwd_param_kernel(GridMeta meta, cons
     }
 }
 
+// Param gradient with run merging.  A wave owns CHUNK consecutive samples (ray order) for
+// 64/F consecutive levels: lane = (level_in_wave, feature).  Each lane walks the chunk serially,
+// keeping the 8 corner sums of its feature in registers while the sample stays in the same grid
+// cell (consecutive samples of a ray are sqrt(3)/1024 apart, so at coarse levels tens of samples
+// share a cell), and flushes them with one atomic per corner when the cell changes.  This cuts
+// the number of memory-side atomic requests — the resource that bounds this kernel — by the
+// run length, and removes the same-address pile-up on the small coarse levels.
+template <int F, int CHUNK>
+__global__ void __launch_bounds__(256) grid_bwd_param_merge_kernel(GridMeta meta, const float* __restrict__ x,
+                                                                   const float* __restrict__ dL_dy, int64_t lddy,
+                                                                   int64_t n, float* __restrict__ dtable)
+{
+    constexpr int LV = 64 / F;       // levels per wave
+    constexpr int SUB = 8;           // samples whose loads are issued together
+    const uint32_t L = meta.n_levels;
+    const uint32_t waves_per_chunk = (L + LV - 1) / LV;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t chunk = __builtin_amdgcn_readfirstlane((int)(wave_global / waves_per_chunk));
+    const uint32_t lg = __builtin_amdgcn_readfirstlane((int)(wave_global % waves_per_chunk));
+    const int lane = threadIdx.x & 63;
+    const uint32_t level = lg * LV + lane / F;
+    const int f = lane % F;
+    const int64_t s0 = chunk * CHUNK;
+    if (s0 >= n) return;
+    const int64_t s1 = s0 + CHUNK < n ? s0 + CHUNK : n;
+    const bool active = level < L;
+    const LevelInfo li = level_info(meta, active ? level : 0);
+    const size_t ld = (size_t)lddy;
+
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = 0.0f;
+    uint32_t b0 = 0, b1 = 0, b2 = 0;
+    bool have = false;
+
+    auto flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (acc[k] != 0.0f) {
+                const uint32_t row = row_index(li, b0 + (k & 1), b1 + ((k >> 1) & 1), b2 + ((k >> 2) & 1));
+                atomicAdd(dtable + (size_t)row * F + f, acc[k]);
+            }
+            acc[k] = 0.0f;
+        }
+    };
+
+    for (int64_t sb = s0; sb < s1; sb += SUB) {
+        float g[SUB], px[SUB], py[SUB], pz[SUB];
+#pragma unroll
+        for (int j = 0; j < SUB; j++) {
+            const int64_t s = sb + j < s1 ? sb + j : s1 - 1;
+            g[j] = active ? dL_dy[(size_t)s * ld + level * F + f] : 0.0f;
+            px[j] = x[3 * s]; py[j] = x[3 * s + 1]; pz[j] = x[3 * s + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < SUB; j++) {
+            if (sb + j >= s1) break;
+            const float p0 = fmaf(li.scale, px[j], 0.5f), p1 = fmaf(li.scale, py[j], 0.5f), p2 = fmaf(li.scale, pz[j], 0.5f);
+            const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+            const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
+            const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+            if (!(have && g0 == b0 && g1 == b1 && g2 == b2)) {
+                if (have) flush();
+                b0 = g0; b1 = g1; b2 = g2; have = true;
+            }
+            const float gv = g[j];
+            const float x0 = (1 - w0) * gv, x1 = w0 * gv;
+            const float y0 = 1 - w1, y1 = w1, z0 = 1 - w2, z1 = w2;
+            acc[0] = fmaf(x0 * y0, z0, acc[0]); acc[1] = fmaf(x1 * y0, z0, acc[1]);
+            acc[2] = fmaf(x0 * y1, z0, acc[2]); acc[3] = fmaf(x1 * y1, z0, acc[3]);
+            acc[4] = fmaf(x0 * y0, z1, acc[4]); acc[5] = fmaf(x1 * y0, z1, acc[5]);
+            acc[6] = fmaf(x0 * y1, z1, acc[6]); acc[7] = fmaf(x1 * y1, z1, acc[7]);
+        }
+    }
+    if (have) flush();
+}
+
 // ------------------------------------------------------------------ input gradient (H3)
 // GROUP = lanes that belong to one sample (L * LPI, a power of two <= 64): their partial
 // (dx,dy,dz) are summed with xor-shuffles and lane 0 of the group stores the result.
 template <int F, int GROUP>
 __global__ void __launch_bounds__(256) grid_bwd_input_kernel(GridMeta meta, const float* __restrict__ table,
                                                              const float* __restrict__ x,
-                                                             const float* __restrict__ dL_dy, int64_t n_items,
-                                                             float* __restrict__ dL_dx)
+                                                             const float* __restrict__ dL_dy, int64_t lddy,
+                                                             int64_t n_items, float* __restrict__ dL_dx)
 {
     constexpr int V = F >= 4 ? 4 : F;
     constexpr int LPI = F / V;
@@ -190,7 +268,7 @@ __global__ void __launch_bounds__(256) grid_bwd_input_kernel(GridMeta meta, cons
         const Cell c = cell_of(x, sample, li.scale);
         float go[V];
         {
-            const vec_t gv = *reinterpret_cast<const vec_t*>(dL_dy + item * F + sub * V);
+            const vec_t gv = *reinterpret_cast<const vec_t*>(dL_dy + sample * lddy + level * F + sub * V);
             const float* gp = reinterpret_cast<const float*>(&gv);
 #pragma unroll
             for (int j = 0; j < V; j++) go[j] = gp[j];
@@ -227,7 +305,7 @@ __global__ void __launch_bounds__(256) grid_bwd_input_kernel(GridMeta meta, cons
 template <int F>
 __global__ void grid_bwd_input_serial_kernel(GridMeta meta, const float* __restrict__ table,
                                              const float* __restrict__ x, const float* __restrict__ dL_dy,
-                                             int64_t n, float* __restrict__ dL_dx)
+                                             int64_t lddy, int64_t n, float* __restrict__ dL_dx)
 {
     const int64_t sample = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (sample >= n) return;
@@ -235,7 +313,7 @@ __global__ void grid_bwd_input_serial_kernel(GridMeta meta, const float* __restr
     for (uint32_t level = 0; level < meta.n_levels; level++) {
         const LevelInfo li = level_info(meta, level);
         const Cell c = cell_of(x, sample, li.scale);
-        const float* go = dL_dy + (sample * meta.n_levels + level) * F;
+        const float* go = dL_dy + sample * lddy + level * F;
         for (int gd = 0; gd < 3; gd++) {
             const int a = (gd + 1) % 3, b = (gd + 2) % 3;
             for (int cc = 0; cc < 4; cc++) {
@@ -262,7 +340,7 @@ __global__ void grid_bwd_input_serial_kernel(GridMeta meta, const float* __restr
 template <int F>
 __global__ void __launch_bounds__(256) grid_bwd_bwd_input_kernel(GridMeta meta, const float* __restrict__ table,
                                                                  const float* __restrict__ x,
-                                                                 const float* __restrict__ dL_dy,
+                                                                 const float* __restrict__ dL_dy, int64_t lddy,
                                                                  const float* __restrict__ v, int64_t n_items,
                                                                  float* __restrict__ dtable,
                                                                  float* __restrict__ dL_ddLdy)
@@ -277,7 +355,7 @@ __global__ void __launch_bounds__(256) grid_bwd_bwd_input_kernel(GridMeta meta, 
     const LevelInfo li = level_info(meta, level);
     const Cell c = cell_of(x, sample, li.scale);
     const float vx = v[3 * sample] * li.scale, vy = v[3 * sample + 1] * li.scale, vz = v[3 * sample + 2] * li.scale;
-    const float g = dL_dy[item * F + f];
+    const float g = dL_dy[sample * lddy + level * F + f];
     float ddy = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -315,7 +393,7 @@ __device__ __forceinline__ void sh_eval(float x, float y, float z, int degree, f
 }
 
 template <int DEG>
-__global__ void sh_fwd_kernel(const float* __restrict__ xin, int64_t n, float* __restrict__ y)
+__global__ void sh_fwd_kernel(const float* __restrict__ xin, int64_t n, float* __restrict__ y, int64_t ldy)
 {
     constexpr int D = DEG * DEG;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -323,7 +401,7 @@ __global__ void sh_fwd_kernel(const float* __restrict__ xin, int64_t n, float* _
     float o[16];
     sh_eval(xin[3 * i] * 2 - 1, xin[3 * i + 1] * 2 - 1, xin[3 * i + 2] * 2 - 1, DEG, o);
 #pragma unroll
-    for (int k = 0; k < D; k++) y[i * D + k] = o[k];
+    for (int k = 0; k < D; k++) y[i * ldy + k] = o[k];
 }
 
 // dL_dx of the SH basis (includes the factor 2 of the [0,1] -> [-1,1] remap)
@@ -387,14 +465,14 @@ bool make_meta(const ngp_grid_desc* d, GridMeta& m)
 }
 
 template <int F>
-void launch_bwd_input(const GridMeta& m, const float* table, const float* x, const float* dL_dy, int64_t n,
-                      float* dL_dx, hipStream_t st)
+void launch_bwd_input(const GridMeta& m, const float* table, const float* x, const float* dL_dy, int64_t lddy,
+                      int64_t n, float* dL_dx, hipStream_t st)
 {
     constexpr int LPI = F >= 4 ? F / 4 : 1;
     const int64_t n_items = n * m.n_levels;
     const int group = (int)m.n_levels * LPI;
     const dim3 grid(ngp_blocks(n_items * LPI, 256));
-#define BWD_IN(G) hipLaunchKernelGGL((grid_bwd_input_kernel<F, G>), grid, dim3(256), 0, st, m, table, x, dL_dy, n_items, dL_dx)
+#define BWD_IN(G) hipLaunchKernelGGL((grid_bwd_input_kernel<F, G>), grid, dim3(256), 0, st, m, table, x, dL_dy, lddy, n_items, dL_dx)
     switch (group) {
         case 1: BWD_IN(1); break;
         case 2: BWD_IN(2); break;
@@ -405,7 +483,7 @@ void launch_bwd_input(const GridMeta& m, const float* table, const float* x, con
         case 64: BWD_IN(64); break;
         default:
             hipLaunchKernelGGL(grid_bwd_input_serial_kernel<F>, dim3(ngp_blocks(n, 256)), dim3(256), 0, st, m, table, x,
-                               dL_dy, n, dL_dx);
+                               dL_dy, lddy, n, dL_dx);
     }
 #undef BWD_IN
 }
@@ -448,10 +526,21 @@ int64_t ngp_grid_layout(int n_levels, int n_features, int log2_hashmap_size, int
         default: return NGP_EINVAL;          \
     }
 
-int ngp_grid_fwd(const ngp_grid_desc* desc, const float* table, const float* x, int64_t n, float* y, void* stream)
+static bool ld_ok(const GridMeta& m, int64_t ld, const void* p)
+{
+    const int64_t w = (int64_t)m.n_levels * m.n_features;
+    if (ld < w) return false;
+    if (m.n_features >= 4) return (ld % 4 == 0) && (((uintptr_t)p & 15) == 0);
+    if (m.n_features == 2) return (ld % 2 == 0) && (((uintptr_t)p & 7) == 0);
+    return true;
+}
+
+int ngp_grid_fwd(const ngp_grid_desc* desc, const float* table, const float* x, int64_t n, float* y, int64_t ldy,
+                 void* stream)
 {
     GridMeta m;
     if (!make_meta(desc, m) || n < 0) return NGP_EINVAL;
+    if (n > 0 && !ld_ok(m, ldy, y)) return NGP_EINVAL;
     if (n == 0) return NGP_OK;
     if (!table || !x || !y) return NGP_EINVAL;
     const int64_t n_items = n * m.n_levels;
@@ -459,67 +548,78 @@ int ngp_grid_fwd(const ngp_grid_desc* desc, const float* table, const float* x, 
     GRID_DISPATCH_F(m.n_features, {
         constexpr int LPI = F >= 4 ? F / 4 : 1;
         hipLaunchKernelGGL(grid_fwd_kernel<F>, dim3(ngp_blocks(n_items * LPI, 256)), dim3(256), 0, st, m, table, x,
-                           n_items, y);
+                           n_items, y, ldy);
     });
     return ngp_check_launch();
 }
 
-int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* dL_dy, int64_t n, float* dtable,
-                       void* stream)
+int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* dL_dy, int64_t lddy, int64_t n,
+                       float* dtable, void* stream)
 {
     GridMeta m;
     if (!make_meta(desc, m) || n < 0) return NGP_EINVAL;
+    if (n > 0 && lddy < (int64_t)m.n_levels * m.n_features) return NGP_EINVAL;
     if (n == 0) return NGP_OK;
     if (!x || !dL_dy || !dtable) return NGP_EINVAL;
     const int64_t n_items = n * m.n_levels;
     hipStream_t st = (hipStream_t)stream;
     GRID_DISPATCH_F(m.n_features, {
-        hipLaunchKernelGGL(grid_bwd_param_kernel<F>, dim3(ngp_blocks(n_items * F, 256)), dim3(256), 0, st, m, x,
-                           dL_dy, n_items, dtable);
+        constexpr int CHUNK = 32;
+        constexpr int LV = 64 / F;
+        const int64_t waves = ((n + CHUNK - 1) / CHUNK) * ((m.n_levels + LV - 1) / LV);
+        if (getenv("NGP_GRID_BWD_SIMPLE")) // one atomic per (sample, level, corner, feature): kept for A/B timing
+            hipLaunchKernelGGL(grid_bwd_param_kernel<F>, dim3(ngp_blocks(n_items * F, 256)), dim3(256), 0, st, m, x,
+                               dL_dy, lddy, n_items, dtable);
+        else
+            hipLaunchKernelGGL((grid_bwd_param_merge_kernel<F, CHUNK>), dim3(ngp_blocks(waves * 64, 256)), dim3(256), 0,
+                               st, m, x, dL_dy, lddy, n, dtable);
     });
     return ngp_check_launch();
 }
 
-int ngp_grid_bwd_input(const ngp_grid_desc* desc, const float* table, const float* x, const float* dL_dy, int64_t n,
-                       float* dL_dx, void* stream)
+int ngp_grid_bwd_input(const ngp_grid_desc* desc, const float* table, const float* x, const float* dL_dy,
+                       int64_t lddy, int64_t n, float* dL_dx, void* stream)
 {
     GridMeta m;
     if (!make_meta(desc, m) || n < 0) return NGP_EINVAL;
+    if (n > 0 && !ld_ok(m, lddy, dL_dy)) return NGP_EINVAL;
     if (n == 0) return NGP_OK;
     if (!table || !x || !dL_dy || !dL_dx) return NGP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    GRID_DISPATCH_F(m.n_features, { launch_bwd_input<F>(m, table, x, dL_dy, n, dL_dx, st); });
+    GRID_DISPATCH_F(m.n_features, { launch_bwd_input<F>(m, table, x, dL_dy, lddy, n, dL_dx, st); });
     return ngp_check_launch();
 }
 
 int ngp_grid_bwd_bwd_input(const ngp_grid_desc* desc, const float* table, const float* x, const float* dL_dy,
-                           const float* dL_ddLdx, int64_t n, float* dtable, float* dL_ddLdy, void* stream)
+                           int64_t lddy, const float* dL_ddLdx, int64_t n, float* dtable, float* dL_ddLdy,
+                           void* stream)
 {
     GridMeta m;
     if (!make_meta(desc, m) || n < 0) return NGP_EINVAL;
+    if (n > 0 && lddy < (int64_t)m.n_levels * m.n_features) return NGP_EINVAL;
     if (n == 0) return NGP_OK;
     if (!table || !x || !dL_dy || !dL_ddLdx) return NGP_EINVAL;
     const int64_t n_items = n * m.n_levels;
     hipStream_t st = (hipStream_t)stream;
     GRID_DISPATCH_F(m.n_features, {
         hipLaunchKernelGGL(grid_bwd_bwd_input_kernel<F>, dim3(ngp_blocks(n_items * F, 256)), dim3(256), 0, st, m,
-                           table, x, dL_dy, dL_ddLdx, n_items, dtable, dL_ddLdy);
+                           table, x, dL_dy, lddy, dL_ddLdx, n_items, dtable, dL_ddLdy);
     });
     return ngp_check_launch();
 }
 
-int ngp_sh_fwd(const float* x, int64_t n, int degree, float* y, void* stream)
+int ngp_sh_fwd(const float* x, int64_t n, int degree, float* y, int64_t ldy, void* stream)
 {
-    if (n < 0 || degree < 1 || degree > 4) return NGP_EINVAL;
+    if (n < 0 || degree < 1 || degree > 4 || ldy < degree * degree) return NGP_EINVAL;
     if (n == 0) return NGP_OK;
     if (!x || !y) return NGP_EINVAL;
     const dim3 grid(ngp_blocks(n, 256));
     hipStream_t st = (hipStream_t)stream;
     switch (degree) {
-        case 1: hipLaunchKernelGGL(sh_fwd_kernel<1>, grid, dim3(256), 0, st, x, n, y); break;
-        case 2: hipLaunchKernelGGL(sh_fwd_kernel<2>, grid, dim3(256), 0, st, x, n, y); break;
-        case 3: hipLaunchKernelGGL(sh_fwd_kernel<3>, grid, dim3(256), 0, st, x, n, y); break;
-        default: hipLaunchKernelGGL(sh_fwd_kernel<4>, grid, dim3(256), 0, st, x, n, y); break;
+        case 1: hipLaunchKernelGGL(sh_fwd_kernel<1>, grid, dim3(256), 0, st, x, n, y, ldy); break;
+        case 2: hipLaunchKernelGGL(sh_fwd_kernel<2>, grid, dim3(256), 0, st, x, n, y, ldy); break;
+        case 3: hipLaunchKernelGGL(sh_fwd_kernel<3>, grid, dim3(256), 0, st, x, n, y, ldy); break;
+        default: hipLaunchKernelGGL(sh_fwd_kernel<4>, grid, dim3(256), 0, st, x, n, y, ldy); break;
     }
     return ngp_check_launch();
 }

@@ -28,6 +28,7 @@ struct GemmArgs {
     int act;
     int64_t k_chunk;      // WGRAD: K range per blockIdx.z
     int vecA, vecB;       // 16-byte vector loads legal for the operand
+    int accumulate;       // DGRAD: C += result
 };
 
 __device__ __forceinline__ float act_fwd(float v, int act)
@@ -168,6 +169,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs p)
                     if (p.z_pre) p.z_pre[m * p.N + n] = v;
                     p.C[m * p.ldc + n] = act_fwd(v, p.act);
                 } else if (MODE == MODE_DGRAD) {
+                    if (p.accumulate) v += p.C[m * p.ldc + n];
                     p.C[m * p.ldc + n] = v;
                 } else {
                     atomicAdd(p.C + m * p.ldc + n, v);
@@ -204,13 +206,14 @@ __global__ void skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx, cons
 }
 
 __global__ void skinny_dgrad_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ W, int64_t ldw,
-                                    int64_t n, int n_in, int n_out, float* __restrict__ dx, int64_t lddx)
+                                    int64_t n, int n_in, int n_out, float* __restrict__ dx, int64_t lddx,
+                                    int accumulate)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * n_in) return;
     const int64_t row = i / n_in;
     const int k = (int)(i - row * n_in);
-    float v = 0.0f;
+    float v = accumulate ? dx[row * lddx + k] : 0.0f;
     for (int o = 0; o < n_out; o++) v = fmaf(dz[row * lddz + o], W[o * ldw + k], v);
     dx[row * lddx + k] = v;
 }
@@ -234,17 +237,25 @@ __global__ void skinny_wgrad_kernel(const float* __restrict__ dz, int64_t lddz, 
     }
 }
 
-// db[j] += sum_rows dz[row][j]
-__global__ void colsum_kernel(const float* __restrict__ dz, int64_t lddz, int64_t n, int n_out, int rows_per_block,
-                              float* __restrict__ db)
+// db[j] += sum_rows dz[row][j].  256 threads = (256/CW) row lanes x CW columns (CW = n_out rounded
+// up to a power of two <= 128), LDS tree over the row lanes, one atomic per column per block.
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ dz, int64_t lddz, int64_t n, int n_out,
+                                                     int cw, int rows_per_block, float* __restrict__ db)
 {
+    __shared__ float part[256];
+    const int j = threadIdx.x % cw, rl = threadIdx.x / cw, nrl = 256 / cw;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
-    for (int j = threadIdx.x; j < n_out; j += blockDim.x) {
-        float a = 0.0f;
-        for (int64_t r = r0; r < r1; r++) a += dz[r * lddz + j];
-        atomicAdd(db + j, a);
+    float a = 0.0f;
+    if (j < n_out)
+        for (int64_t r = r0 + rl; r < r1; r += nrl) a += dz[r * lddz + j];
+    part[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = nrl / 2; s > 0; s >>= 1) {
+        if (rl < s) part[threadIdx.x] += part[threadIdx.x + s * cw];
+        __syncthreads();
     }
+    if (rl == 0 && j < n_out) atomicAdd(db + j, part[threadIdx.x]);
 }
 
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yz, int64_t count, int act,
@@ -257,11 +268,60 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
         switch (act) {
             case NGP_ACT_RELU: v = yz[i] > 0.0f ? g : 0.0f; break;
             case NGP_ACT_SIGMOID: { const float s = yz[i]; v = g * s * (1.0f - s); } break;
-            case NGP_ACT_SOFTPLUS: { const float z = yz[i]; v = z > 20.0f ? g : g / (1.0f + __expf(-z)); } break;
+            case NGP_ACT_SOFTPLUS: v = g * -expm1f(-yz[i]); break; // sigmoid(z) = 1 - exp(-softplus(z))
             case NGP_ACT_EXP: v = g * yz[i]; break;
             default: v = g;
         }
         dz[i] = v;
+    }
+}
+
+
+// derivative of an activation expressed through its OUTPUT y
+__device__ __forceinline__ float act_grad_from_output(float y, int act)
+{
+    switch (act) {
+        case NGP_ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
+        case NGP_ACT_SIGMOID: return y * (1.0f - y);
+        case NGP_ACT_SOFTPLUS: return -expm1f(-y);
+        case NGP_ACT_EXP: return y;
+        default: return 1.0f;
+    }
+}
+
+// Hidden-layer backward of a 2-layer MLP whose output layer is narrow (n_out <= 16):
+//   dz2[n][o] = dOut[n][o] * act2'(out[n][o])          (written to dz2, row stride lddz2)
+//   dz1[n][j] = (sum_o dz2[n][o] * W2[o][j]) * act1'(hidden[n][j])
+// Thread = hidden column j, W2's column in registers, rows strided over the grid.  Replaces an
+// MFMA dgrad with K <= 16 plus two elementwise passes; purely bandwidth bound.
+// dOut == nullptr means "all ones" (the d(sigma)/dx pass of the density head).
+template <int OMAX>
+__global__ void __launch_bounds__(256) mlp_hidden_bwd_kernel(const float* __restrict__ dOut, int64_t lddo,
+                                                             const float* __restrict__ out, int64_t ldo, int act2,
+                                                             const float* __restrict__ W2, int64_t ldw2,
+                                                             const float* __restrict__ hidden, int64_t ldh, int act1,
+                                                             int64_t n, int H, int n_out,
+                                                             float* __restrict__ dz2, int64_t lddz2,
+                                                             float* __restrict__ dz1, int64_t lddz1)
+{
+    const int rows_per_block = 256 / H;   // H is 32, 64 or 128
+    const int j = threadIdx.x % H;
+    const int rsub = threadIdx.x / H;
+    float w[OMAX];
+#pragma unroll
+    for (int o = 0; o < OMAX; o++) w[o] = o < n_out ? W2[o * ldw2 + j] : 0.0f;
+    for (int64_t row = (int64_t)blockIdx.x * rows_per_block + rsub; row < n; row += (int64_t)gridDim.x * rows_per_block) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int o = 0; o < OMAX; o++) {
+            if (o < n_out) {
+                const float g = dOut ? dOut[row * lddo + o] : 1.0f;
+                const float d = g * act_grad_from_output(out[row * ldo + o], act2);
+                acc = fmaf(d, w[o], acc);
+                if (dz2 && j == o) dz2[row * lddz2 + o] = d;
+            }
+        }
+        dz1[row * lddz1 + j] = acc * act_grad_from_output(hidden[row * ldh + j], act1);
     }
 }
 
@@ -360,7 +420,7 @@ int ngp_linear_fwd(const float* x, int64_t ldx, const float* W, int64_t ldw, con
 }
 
 int ngp_linear_bwd_input(const float* dz, int64_t lddz, const float* W, int64_t ldw, int64_t n, int n_in, int n_out,
-                         float* dx, int64_t lddx, void* stream)
+                         float* dx, int64_t lddx, int accumulate, void* stream)
 {
     if (n < 0 || n_in < 1 || n_out < 1 || lddz < n_out || ldw < n_in || lddx < n_in) return NGP_EINVAL;
     if (n == 0) return NGP_OK;
@@ -368,12 +428,12 @@ int ngp_linear_bwd_input(const float* dz, int64_t lddz, const float* W, int64_t 
     hipStream_t st = (hipStream_t)stream;
     if (n_out <= 4) {
         hipLaunchKernelGGL(skinny_dgrad_kernel, dim3(ngp_blocks(n * n_in, 256)), dim3(256), 0, st, dz, lddz, W, ldw, n,
-                           n_in, n_out, dx, lddx);
+                           n_in, n_out, dx, lddx, accumulate);
         return ngp_check_launch();
     }
     GemmArgs p{};
     p.A = dz; p.lda = lddz; p.B = W; p.ldb = ldw; p.C = dx; p.ldc = lddx;
-    p.M = n; p.N = n_in; p.K = n_out; p.act = 0; p.k_chunk = 0;
+    p.M = n; p.N = n_in; p.K = n_out; p.act = 0; p.k_chunk = 0; p.accumulate = accumulate;
     p.vecA = aligned16(dz) && (lddz % 4 == 0); p.vecB = aligned16(W) && (ldw % 4 == 0);
     if (n_in > 32) {
         dim3 grid(ngp_blocks(n, 128), ngp_blocks(n_in, 128));
@@ -393,9 +453,11 @@ int ngp_linear_bwd_weight(const float* dz, int64_t lddz, const float* x, int64_t
     if (!dz || !x || !dW) return NGP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (db) {
-        const int rpb = 1024;
-        hipLaunchKernelGGL(colsum_kernel, dim3(ngp_blocks(n, rpb)), dim3(n_out >= 128 ? 128 : 64), 0, st, dz, lddz, n,
-                           n_out, rpb, db);
+        if (n_out > 128) return NGP_EINVAL;
+        int cw = 1;
+        while (cw < n_out) cw <<= 1;
+        const int rpb = 4096;
+        hipLaunchKernelGGL(colsum_kernel, dim3(ngp_blocks(n, rpb)), dim3(256), 0, st, dz, lddz, n, n_out, cw, rpb, db);
     }
     if (n_out <= 4) {
         const int rpb = 512;
@@ -442,6 +504,26 @@ int ngp_act_bwd(const float* dy, const float* y_or_z, int64_t count, int activat
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y_or_z, count,
                        activation, dz);
+    return ngp_check_launch();
+}
+
+int ngp_mlp_hidden_bwd(const float* dOut, int64_t lddo, const float* out, int64_t ldo, int act2, const float* W2,
+                       int64_t ldw2, const float* hidden, int64_t ldh, int act1, int64_t n, int H, int n_out,
+                       float* dz2, int64_t lddz2, float* dz1, int64_t lddz1, void* stream)
+{
+    if (n < 0 || n_out < 1 || n_out > 16 || !(H == 32 || H == 64 || H == 128)) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!out || !W2 || !hidden || !dz1) return NGP_EINVAL;
+    const int rows_per_block = 256 / H;
+    int64_t blocks = (n + rows_per_block - 1) / rows_per_block;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_out <= 4)
+        hipLaunchKernelGGL(mlp_hidden_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, dOut, lddo, out, ldo, act2,
+                           W2, ldw2, hidden, ldh, act1, n, H, n_out, dz2, lddz2, dz1, lddz1);
+    else
+        hipLaunchKernelGGL(mlp_hidden_bwd_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, dOut, lddo, out, ldo, act2,
+                           W2, ldw2, hidden, ldh, act1, n, H, n_out, dz2, lddz2, dz1, lddz1);
     return ngp_check_launch();
 }
 

@@ -57,7 +57,7 @@ class _LinearAct(Function):
         dz = dy.contiguous()
         if act != 0:
             dz = torch.empty_like(dz)
-            call("act_bwd", dy.contiguous(), z if act == _SOFTPLUS else y, dz.numel(), act, dz)
+            call("act_bwd", dy.contiguous(), y, dz.numel(), act, dz)
         dx = dW = db = None
         if ctx.needs_input_grad[1]:
             dW = torch.zeros_like(W)
@@ -65,8 +65,180 @@ class _LinearAct(Function):
             call("linear_bwd_weight", dz, no, x, ni, n, ni, no, dW, ni, db)
         if ctx.needs_input_grad[0]:
             dx = torch.empty(n, ni, dtype=_f32, device=x.device)
-            call("linear_bwd_input", dz, no, W, ni, n, ni, no, dx, ni)
+            call("linear_bwd_input", dz, no, W, ni, n, ni, no, dx, ni, 0)
         return dx, dW, db, None
+
+
+_RELU, _NONE = 1, 0
+
+
+def _mlp2_backward(d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, ld_in, n_in, W1, ldw1, dW1, dW2,
+                   db1, db2, dx, ld_dx, dx_cols, w1_col0, accumulate):
+    """Backward of a 2-layer MLP (x_in -> H hidden with act1 -> n_out with act2) on the library:
+    dz2/dz1 by the fused hidden-backward kernel, three MFMA/VALU products for dW2, dW1 and dx.
+    dx receives dz1 . W1[:, w1_col0 : w1_col0+dx_cols] (the input columns that need a gradient)."""
+    n = hidden.shape[0]
+    dev = hidden.device
+    dz2 = torch.empty(n, 16 if n_out > 4 else 4, dtype=_f32, device=dev)
+    dz1 = torch.empty(n, H, dtype=_f32, device=dev)
+    call("mlp_hidden_bwd", d_out, d_out.stride(0), out, ld_out, act2, W2, H, hidden, H, act1, n, H, n_out,
+         dz2, dz2.shape[1], dz1, H)
+    call("linear_bwd_weight", dz2, dz2.shape[1], hidden, H, n, H, n_out, dW2, H, db2)
+    call("linear_bwd_weight", dz1, H, x_in, ld_in, n, n_in, H, dW1, ldw1, db1)
+    if dx is not None:
+        call("linear_bwd_input", dz1, H, W1[w1_col0:] if W1.dim() == 1 else W1, ldw1, n, dx_cols, H, dx, ld_dx,
+             1 if accumulate else 0)
+    return dz1
+
+
+class _FieldFn(Function):
+    """The whole NGP field (networks.py:198-240) as one autograd node: explicit kernel launches on
+    preallocated buffers, no concat (both encoders write straight into rgb_net's input matrix),
+    analytic d(sigma)/dx, and a backward that runs only the branches whose outputs received a
+    gradient (normal / semantic heads are skipped when the loss does not use them).
+
+    inputs : x (N,3) world, d (N,3), embed_a (N,E) or None, then the 9 parameter tensors
+    outputs: sigma (N), rgb (N,3) [after rgb_net's output activation], dsigma_dx (N,3) [no grad],
+             normal head (N,3) raw, semantic logits (N,C)
+    """
+
+    @staticmethod
+    def forward(ctx, model, x, d, embed_a, xyz_table, W1, b1, W2, b2, rgb_table, rgb_p, nrm_p, sem_p):
+        n = x.shape[0]
+        dev = x.device
+        xe, re = model.xyz_encoder, model.rgb_encoder
+        C = model.semantic_header.n_output_dims
+        E = 0 if embed_a is None else embed_a.shape[1]
+        K = 144 + E
+        Kp = model.rgb_net.padded_in
+        span = model.xyz_max - model.xyz_min
+        xn = ((x - model.xyz_min) / span).contiguous()
+
+        # density head
+        feat = torch.empty(n, 128, dtype=_f32, device=dev)
+        call("grid_fwd", xe.desc, xyz_table, xn, n, feat, 128)
+        a1 = torch.empty(n, 128, dtype=_f32, device=dev)
+        call("linear_fwd", feat, 128, W1, 128, b1, n, 128, 128, _SOFTPLUS, a1, 128, None)
+        sig = torch.empty(n, 1, dtype=_f32, device=dev)
+        call("linear_fwd", a1, 128, W2, 128, b2, n, 128, 1, _SOFTPLUS, sig, 1, None)
+        # analytic d(sigma)/dx: back-substitute ones through the head, then the grid input gradient
+        dz1 = torch.empty(n, 128, dtype=_f32, device=dev)
+        call("mlp_hidden_bwd", None, 0, sig, 1, _SOFTPLUS, W2, 128, a1, 128, _SOFTPLUS, n, 128, 1, None, 0, dz1, 128)
+        dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
+        call("linear_bwd_input", dz1, 128, W1, 128, n, 128, 128, dfeat, 128, 0)
+        grads = torch.empty(n, 3, dtype=_f32, device=dev)
+        call("grid_bwd_input", xe.desc, xyz_table, xn, dfeat, 128, n, grads)
+        grads = grads / span
+        del dz1, dfeat
+
+        # colour branch: [SH(16) | rgb grid features (128) | appearance code (E) | ones-padding]
+        rgb_in = torch.empty(n, Kp, dtype=_f32, device=dev)
+        dn = F.normalize(d, p=2, dim=-1, eps=1e-6)
+        call("sh_fwd", ((dn + 1) / 2).contiguous(), n, 4, rgb_in, Kp)
+        call("grid_fwd", re.desc, rgb_table, xn, n, rgb_in[:, 16:], Kp)
+        if E:
+            rgb_in[:, 144:K] = embed_a
+        if Kp > K:
+            rgb_in[:, K:] = 1.0
+        feat_rgb = rgb_in[:, 16:144]
+        net = model.rgb_net
+        a_r = torch.empty(n, 128, dtype=_f32, device=dev)
+        call("linear_fwd", rgb_in, Kp, rgb_p, Kp, None, n, Kp, 128, _RELU, a_r, 128, None)
+        rgb_o = torch.empty(n, 3, dtype=_f32, device=dev)
+        call("linear_fwd", a_r, 128, rgb_p[128 * Kp:], 128, None, n, 128, 3, net.output_activation, rgb_o, 3, None)
+        a_n = torch.empty(n, 32, dtype=_f32, device=dev)
+        call("linear_fwd", feat_rgb, Kp, nrm_p, 128, None, n, 128, 32, _RELU, a_n, 32, None)
+        np_o = torch.empty(n, 3, dtype=_f32, device=dev)
+        call("linear_fwd", a_n, 32, nrm_p[32 * 128:], 32, None, n, 32, 3, _NONE, np_o, 3, None)
+        a_s = torch.empty(n, 32, dtype=_f32, device=dev)
+        call("linear_fwd", feat_rgb, Kp, sem_p, 128, None, n, 128, 32, _RELU, a_s, 32, None)
+        sem_o = torch.empty(n, C, dtype=_f32, device=dev)
+        call("linear_fwd", a_s, 32, sem_p[32 * 128:], 32, None, n, 32, C, _NONE, sem_o, C, None)
+
+        ctx.model = model
+        ctx.E, ctx.K, ctx.Kp, ctx.C = E, K, Kp, C
+        ctx.save_for_backward(xn, feat, a1, sig, rgb_in, a_r, rgb_o, a_n, np_o, a_s, sem_o,
+                              xyz_table, W1, W2, rgb_table, rgb_p, nrm_p, sem_p)
+        ctx.mark_non_differentiable(grads)
+        ctx.set_materialize_grads(False)
+        return sig[:, 0], rgb_o, grads, np_o, sem_o
+
+    @staticmethod
+    def backward(ctx, d_sig, d_rgb, _d_grads, d_np, d_sem):
+        (xn, feat, a1, sig, rgb_in, a_r, rgb_o, a_n, np_o, a_s, sem_o,
+         xyz_table, W1, W2, rgb_table, rgb_p, nrm_p, sem_p) = ctx.saved_tensors
+        model = ctx.model
+        E, K, Kp, C = ctx.E, ctx.K, ctx.Kp, ctx.C
+        n = xn.shape[0]
+        dev = xn.device
+        xe, re = model.xyz_encoder, model.rgb_encoder
+        need = ctx.needs_input_grad  # (model, x, d, embed_a, xyz_table, W1, b1, W2, b2, rgb_table, rgb_p, nrm_p, sem_p)
+        g_x = g_emb = g_xyz = g_W1 = g_b1 = g_W2 = g_b2 = g_rgbt = g_rgbp = g_nrm = g_sem = None
+        span = model.xyz_max - model.xyz_min
+
+        # ---- colour branch (rgb_net + the two heads) -> gradient w.r.t. [grid features | appearance code]
+        dfeat_rgb = None
+        W_cols = 128 + E
+        if d_rgb is not None:
+            g_rgbp = torch.zeros_like(rgb_p)
+            dfeat_rgb = torch.empty(n, W_cols, dtype=_f32, device=dev)
+            _mlp2_backward(d_rgb.contiguous(), rgb_o, 3, model.rgb_net.output_activation, rgb_p[128 * Kp:], a_r, 128, _RELU, 3,
+                           rgb_in, Kp, Kp, rgb_p, Kp, g_rgbp, g_rgbp[128 * Kp:], None, None,
+                           dfeat_rgb, W_cols, W_cols, 16, False)
+        for d_o, p, a_h, out, n_out, slot in ((d_np, nrm_p, a_n, np_o, 3, "nrm"), (d_sem, sem_p, a_s, sem_o, C, "sem")):
+            if d_o is None:
+                continue
+            g_p = torch.zeros_like(p)
+            first = dfeat_rgb is None
+            if first:
+                dfeat_rgb = torch.zeros(n, W_cols, dtype=_f32, device=dev) if E else torch.empty(n, W_cols, dtype=_f32, device=dev)
+            _mlp2_backward(d_o.contiguous(), out, n_out, _NONE, p[32 * 128:], a_h, 32, _RELU, n_out,
+                           rgb_in[:, 16:], Kp, 128, p, 128, g_p, g_p[32 * 128:], None, None,
+                           dfeat_rgb, W_cols, 128, 0, not first)
+            if slot == "nrm":
+                g_nrm = g_p
+            else:
+                g_sem = g_p
+        if dfeat_rgb is not None:
+            if need[9]:
+                buf = getattr(re, "grad_buffer", None)
+                if buf is None:
+                    g_rgbt = torch.zeros_like(rgb_table)
+                    buf = g_rgbt
+                call("grid_bwd_param", re.desc, xn, dfeat_rgb, W_cols, n, buf)
+                cb = getattr(re, "on_grad_ready", None)
+                if cb is not None:
+                    cb()
+            if E and need[3]:
+                g_emb = dfeat_rgb[:, 128:]
+            if need[1]:
+                g_x = torch.empty(n, 3, dtype=_f32, device=dev)
+                call("grid_bwd_input", re.desc, rgb_table, xn, dfeat_rgb, W_cols, n, g_x)
+
+        # ---- density head
+        if d_sig is not None:
+            g_W1, g_W2 = torch.zeros_like(W1), torch.zeros_like(W2)
+            g_b1 = torch.zeros(128, dtype=_f32, device=dev)
+            g_b2 = torch.zeros(1, dtype=_f32, device=dev)
+            dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
+            _mlp2_backward(d_sig.contiguous().view(n, 1), sig, 1, _SOFTPLUS, W2, a1, 128, _SOFTPLUS, 1,
+                           feat, 128, 128, W1, 128, g_W1, g_W2, g_b1, g_b2, dfeat, 128, 128, 0, False)
+            if need[4]:
+                buf = getattr(xe, "grad_buffer", None)
+                if buf is None:
+                    g_xyz = torch.zeros_like(xyz_table)
+                    buf = g_xyz
+                call("grid_bwd_param", xe.desc, xn, dfeat, 128, n, buf)
+                cb = getattr(xe, "on_grad_ready", None)
+                if cb is not None:
+                    cb()
+            if need[1]:
+                gx2 = torch.empty(n, 3, dtype=_f32, device=dev)
+                call("grid_bwd_input", xe.desc, xyz_table, xn, dfeat, 128, n, gx2)
+                g_x = gx2 if g_x is None else g_x + gx2
+        if g_x is not None:
+            g_x = g_x / span
+        return (None, g_x, None, g_emb, g_xyz, g_W1, g_b1, g_W2, g_b2, g_rgbt, g_rgbp, g_nrm, g_sem)
 
 
 class NGP(nn.Module):
@@ -138,62 +310,62 @@ class NGP(nn.Module):
 
     # ------------------------------------------------------------------ density / normals
     def _density_head(self, feat):
-        """feat (N,128) -> sigma (N), plus the pre-activations of both layers."""
+        """feat (N,128) -> sigma (N) through autograd-visible layers (used when a caller wants
+        gradients of density() alone)."""
         lin1, lin2 = self.xyz_net[0], self.xyz_net[2]
-        a1, z1 = _LinearAct.apply(feat, lin1.weight, lin1.bias, _SOFTPLUS)
-        s, h = _LinearAct.apply(a1, lin2.weight, lin2.bias, _SOFTPLUS)
-        return s[:, 0], z1, h
+        a1, _ = _LinearAct.apply(feat, lin1.weight, lin1.bias, _SOFTPLUS)
+        s, _ = _LinearAct.apply(a1, lin2.weight, lin2.bias, _SOFTPLUS)
+        return s[:, 0]
 
     def density(self, x, return_feat=False, grad=True, grad_feat=True):
         """x (N,3) in [-scale, scale] -> sigmas (N) [, feat_rgb (N,128)]"""
-        x = (x - self.xyz_min) / (self.xyz_max - self.xyz_min)
-        with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
-            h = self.xyz_encoder(x)
-            sigmas, _, _ = self._density_head(h)
+        x = ((x - self.xyz_min) / (self.xyz_max - self.xyz_min)).contiguous()
+        if not (grad and torch.is_grad_enabled()):
+            # inference (update_density_grid runs this on 1-2 M points): three launches, no graph
+            with torch.no_grad():
+                n = x.shape[0]
+                lin1, lin2 = self.xyz_net[0], self.xyz_net[2]
+                feat = torch.empty(n, 128, dtype=_f32, device=x.device)
+                call("grid_fwd", self.xyz_encoder.desc, self.xyz_encoder.params, x, n, feat, 128)
+                a1 = torch.empty(n, 128, dtype=_f32, device=x.device)
+                call("linear_fwd", feat, 128, lin1.weight, 128, lin1.bias, n, 128, 128, _SOFTPLUS, a1, 128, None)
+                sig = torch.empty(n, 1, dtype=_f32, device=x.device)
+                call("linear_fwd", a1, 128, lin2.weight, 128, lin2.bias, n, 128, 1, _SOFTPLUS, sig, 1, None)
+                sigmas = sig[:, 0]
+        else:
+            sigmas = self._density_head(self.xyz_encoder(x))
         if return_feat:
             with torch.set_grad_enabled(grad_feat and torch.is_grad_enabled()):
                 feat_rgb = self.rgb_encoder(x)
             return sigmas, feat_rgb
         return sigmas
 
+    def _field(self, x, d, kwargs):
+        """-> sigmas, rgbs (after rgb_net's own output activation), dsigma/dx, raw normal head, semantic logits"""
+        embed_a = None
+        if self.embed_a:
+            embed_a = kwargs['embedding_a']
+            if embed_a.size(0) < x.size(0):
+                embed_a = torch.repeat_interleave(embed_a, int(x.size(0) / embed_a.size(0)), 0)
+            embed_a = embed_a.contiguous()
+        lin1, lin2 = self.xyz_net[0], self.xyz_net[2]
+        return _FieldFn.apply(self, x.contiguous(), d.contiguous(), embed_a,
+                              self.xyz_encoder.params, lin1.weight, lin1.bias, lin2.weight, lin2.bias,
+                              self.rgb_encoder.params, self.rgb_net.params, self.norm_pred_header.params,
+                              self.semantic_header.params)
+
     def grad(self, x):
-        """-> sigmas (N), feat_rgb (N,128), d(sigma)/dx (N,3) (detached, see module docstring)."""
+        """-> sigmas (N), feat_rgb (N,128), d(sigma)/dx (N,3) (detached, see module docstring).
+        Kept for API parity (networks.py:186-196); forward()/forward_test() use the fused node."""
+        sigmas, _, grads, _, _ = self._field(x, torch.zeros_like(x), {'embedding_a': torch.zeros(
+            x.shape[0], self.rgb_net.n_input_dims - 144, device=x.device)} if self.embed_a else {})
         span = self.xyz_max - self.xyz_min
-        xn = ((x - self.xyz_min) / span).contiguous()
-        feat = self.xyz_encoder(xn)
-        sigmas, z1, h = self._density_head(feat)
-        feat_rgb = self.rgb_encoder(xn)
-        with torch.no_grad():
-            n = xn.shape[0]
-            lin1, lin2 = self.xyz_net[0], self.xyz_net[2]
-            ones = torch.ones(n, 1, dtype=_f32, device=x.device)
-            dh = torch.empty_like(ones)
-            call("act_bwd", ones, h, n, _SOFTPLUS, dh)                      # d sigma / d h
-            da1 = torch.empty(n, 128, dtype=_f32, device=x.device)
-            call("linear_bwd_input", dh, 1, lin2.weight, 128, n, 128, 1, da1, 128)
-            dz1 = torch.empty_like(da1)
-            call("act_bwd", da1, z1, da1.numel(), _SOFTPLUS, dz1)
-            dfeat = torch.empty(n, feat.shape[1], dtype=_f32, device=x.device)
-            call("linear_bwd_input", dz1, 128, lin1.weight, feat.shape[1], n, feat.shape[1], 128, dfeat,
-                 feat.shape[1])
-            grads = torch.empty(n, 3, dtype=_f32, device=x.device)
-            call("grid_bwd_input", self.xyz_encoder.desc, self.xyz_encoder.params, xn, dfeat, n, grads)
-            grads = grads / span
+        feat_rgb = self.rgb_encoder(((x - self.xyz_min) / span).contiguous())
         return sigmas, feat_rgb, grads
 
     # ------------------------------------------------------------------ full field
-    def _color(self, d, feat_rgb, kwargs):
-        d = F.normalize(d, p=2, dim=-1, eps=1e-6)
-        d = self.dir_encoder((d + 1) / 2)
-        if self.embed_a:
-            embed_a = kwargs['embedding_a']
-            if embed_a.size(0) < feat_rgb.size(0):
-                repeat = int(feat_rgb.size(0) / embed_a.size(0))
-                embed_a = torch.repeat_interleave(embed_a, repeat, 0)
-            rgbs = self.rgb_net(torch.cat([d, feat_rgb, embed_a], 1))
-        else:
-            rgbs = self.rgb_net(torch.cat([d, feat_rgb], 1))
-        if self.rgb_act == 'None':  # log-radiance
+    def _tone(self, rgbs, kwargs):
+        if self.rgb_act == 'None':  # rgb_net outputs log-radiance
             if kwargs.get('output_radiance', False):
                 rgbs = TruncExp.apply(rgbs)
             else:
@@ -202,23 +374,20 @@ class NGP(nn.Module):
 
     def forward(self, x, d, **kwargs):
         """x, d (N,3) -> sigmas (N), rgbs (N,3), normals_raw (N,3), normals_pred (N,3), semantic (N,C)"""
-        sigmas, feat_rgb, grads = self.grad(x)
+        sigmas, rgbs, grads, np_raw, sem_logits = self._field(x, d, kwargs)
         normals_raw = -F.normalize(grads, p=2, dim=-1, eps=1e-6)
-        normals_pred = -F.normalize(self.norm_pred_header(feat_rgb), p=2, dim=-1, eps=1e-6)
-        semantic = self.semantic_act(self.semantic_header(feat_rgb))
-        rgbs = self._color(d, feat_rgb, kwargs)
-        return sigmas, rgbs, normals_raw, normals_pred, semantic
+        normals_pred = -F.normalize(np_raw, p=2, dim=-1, eps=1e-6)
+        semantic = self.semantic_act(sem_logits)
+        return sigmas, self._tone(rgbs, kwargs), normals_raw, normals_pred, semantic
 
     def forward_test(self, x, d, **kwargs):
         """same as forward but returns (sigmas, rgbs, normals_pred, normals_raw, semantic) — the
-        reference's test path swaps the two normals (networks.py:282)."""
-        sigmas, feat_rgb, grads = self.grad(x)
+        reference's test path swaps the two normals (networks.py:282) and detaches the heads."""
+        sigmas, rgbs, grads, np_raw, sem_logits = self._field(x, d, kwargs)
         normals_raw = -F.normalize(grads, p=2, dim=-1, eps=1e-6)
-        with torch.no_grad():
-            normals_pred = -F.normalize(self.norm_pred_header(feat_rgb), p=2, dim=-1, eps=1e-6)
-            semantic = self.semantic_act(self.semantic_header(feat_rgb))
-        rgbs = self._color(d, feat_rgb, kwargs)
-        return sigmas, rgbs, normals_pred, normals_raw, semantic
+        normals_pred = -F.normalize(np_raw.detach(), p=2, dim=-1, eps=1e-6)
+        semantic = self.semantic_act(sem_logits.detach())
+        return sigmas, self._tone(rgbs, kwargs), normals_pred, normals_raw, semantic
 
     def forward_skybox(self, d):
         if not self.use_skybox:

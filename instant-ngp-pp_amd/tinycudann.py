@@ -32,7 +32,7 @@ class _GridFwd(Function):
     def forward(ctx, x, params, enc):
         x = x.contiguous()
         y = torch.empty(x.shape[0], enc.n_output_dims, dtype=_f32, device=x.device)
-        call("grid_fwd", enc.desc, params, x, x.shape[0], y)
+        call("grid_fwd", enc.desc, params, x, x.shape[0], y, enc.n_output_dims)
         ctx.save_for_backward(x, params)
         ctx.enc = enc
         return y
@@ -49,10 +49,10 @@ class _GridFwd(Function):
             buf = getattr(enc, "grad_buffer", None)
             if buf is not None:
                 # trainer-owned flat gradient: scatter-add straight into it (autograd sees None)
-                call("grid_bwd_param", enc.desc, x, dy, x.shape[0], buf)
+                call("grid_bwd_param", enc.desc, x, dy, enc.n_output_dims, x.shape[0], buf)
             else:
                 dparams = torch.zeros_like(params)
-                call("grid_bwd_param", enc.desc, x, dy, x.shape[0], dparams)
+                call("grid_bwd_param", enc.desc, x, dy, enc.n_output_dims, x.shape[0], dparams)
             cb = getattr(enc, "on_grad_ready", None)
             if cb is not None:
                 cb()
@@ -65,7 +65,7 @@ class _GridBwdInput(Function):
     @staticmethod
     def forward(ctx, dy, x, params, enc):
         dx = torch.empty(x.shape[0], 3, dtype=_f32, device=x.device)
-        call("grid_bwd_input", enc.desc, params, x, dy, x.shape[0], dx)
+        call("grid_bwd_input", enc.desc, params, x, dy, enc.n_output_dims, x.shape[0], dx)
         ctx.save_for_backward(dy, x, params)
         ctx.enc = enc
         return dx
@@ -77,7 +77,7 @@ class _GridBwdInput(Function):
         ddx = ddx.contiguous()
         d_dy = torch.empty_like(dy) if ctx.needs_input_grad[0] else None
         d_params = torch.zeros_like(params) if ctx.needs_input_grad[2] else None
-        call("grid_bwd_bwd_input", enc.desc, params, x, dy, ddx, x.shape[0], d_params, d_dy)
+        call("grid_bwd_bwd_input", enc.desc, params, x, dy, enc.n_output_dims, ddx, x.shape[0], d_params, d_dy)
         return d_dy, None, d_params, None
 
 
@@ -86,7 +86,7 @@ class _SHFwd(Function):
     def forward(ctx, x, degree):
         x = x.contiguous()
         y = torch.empty(x.shape[0], degree * degree, dtype=_f32, device=x.device)
-        call("sh_fwd", x, x.shape[0], degree, y)
+        call("sh_fwd", x, x.shape[0], degree, y, degree * degree)
         ctx.save_for_backward(x)
         ctx.degree = degree
         return y
@@ -209,7 +209,7 @@ class _MLPFn(Function):
                      dparams[offs[li]:offs[li + 1]], ni, None)
             if li > 0 or need_x:
                 g = torch.empty(n, ni, dtype=_f32, device=dy.device)
-                call("linear_bwd_input", dz, no, W, ni, n, ni, no, g, ni)
+                call("linear_bwd_input", dz, no, W, ni, n, ni, no, g, ni, 0)
                 if li == 0:
                     dx = g
         return dx, dparams, None

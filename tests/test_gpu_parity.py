@@ -419,7 +419,7 @@ def test_linear_layers(ngp, n, n_in, n_out, act, bias):
     close(N(z), zref, 2e-5, 2e-5)
     dz = g.normal(size=(n, n_out)).astype(np.float32)
     dx = torch.empty(n, n_in, device=DEV)
-    call("linear_bwd_input", T(dz), n_out, T(W), n_in, n, n_in, n_out, dx, n_in)
+    call("linear_bwd_input", T(dz), n_out, T(W), n_in, n, n_in, n_out, dx, n_in, 0)
     close(N(dx), dz.astype(np.float64) @ W64, 3e-5, 3e-5)
     dW = torch.zeros(n_out, n_in, device=DEV)
     db = torch.zeros(n_out, device=DEV)
@@ -470,3 +470,103 @@ def test_adam_matches_torch(ngp):
         ngp._lib.call("adam_step", p, gbuf, m, v, n, 1e-2, 0.9, 0.999, 1e-8, 0.0, step, None, 1)
         assert not gbuf.any()
     close(N(p), N(p_ref), 1e-5, 1e-6)
+
+
+# ---------------------------------------------------------------------------- NGP field (fused node)
+def _make_model(ngp, embed_a=False, table_scale=0.3):
+    torch.manual_seed(5)
+    model = ngp.networks.NGP(scale=0.5, embed_a=embed_a, embed_a_len=8).to(DEV)
+    with torch.no_grad():  # tcnn's 1e-4 init makes every feature ~0: use O(1) tables for a real test
+        model.xyz_encoder.params.uniform_(-table_scale, table_scale)
+        model.rgb_encoder.params.uniform_(-table_scale, table_scale)
+    return model
+
+
+def test_field_forward_matches_oracle(ngp):
+    from oracle.field import CpuNGP
+    model = _make_model(ngp)
+    g = rng(200)
+    n = 1500
+    x = ((g.random((n, 3)) - 0.5) * 0.98).astype(np.float32)
+    d = g.normal(size=(n, 3)).astype(np.float32)
+    with torch.no_grad():
+        sig, rgb, n_raw, n_pred, sem = model(T(x), T(d))
+        sig_t, rgb_t, n_pred_t, n_raw_t, sem_t = model.forward_test(T(x), T(d))
+        dens = model.density(T(x))
+    state = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    ref = CpuNGP(state, scale=0.5)
+    rs, rrgb, rn_raw, rn_pred, rsem, _ = ref(x, d)
+    close(N(sig), rs, 1e-4, 1e-5)
+    close(N(dens), rs, 1e-4, 1e-5)
+    close(N(rgb), rrgb, 1e-4, 1e-5)
+    close(N(n_pred), rn_pred, 1e-3, 1e-4)
+    close(N(sem), rsem, 1e-4, 1e-5)
+    # unit normals from d(sigma)/dx: compare direction
+    cos = (N(n_raw) * rn_raw).sum(-1)
+    assert np.percentile(cos, 1) > 0.9999
+    # test path returns the same values with the two normals swapped
+    assert torch.equal(sig, sig_t) and torch.equal(rgb, rgb_t)
+    assert torch.equal(n_pred, n_pred_t) and torch.equal(n_raw, n_raw_t) and torch.equal(sem, sem_t)
+
+
+@pytest.mark.parametrize("embed_a", [False, True])
+def test_field_backward_matches_torch_fp64(ngp, embed_a):
+    """The fused node's parameter gradients against an fp64 torch re-implementation of the same
+    field built on the (separately verified) grid encoder."""
+    model = _make_model(ngp, embed_a=embed_a)
+    g = rng(210)
+    n = 700
+    x = T(((g.random((n, 3)) - 0.5) * 0.98).astype(np.float32))
+    d = T(g.normal(size=(n, 3)).astype(np.float32))
+    kw = {"embedding_a": T(g.normal(size=(n, 8)).astype(np.float32)).requires_grad_(True)} if embed_a else {}
+    ws = [T(g.normal(size=s).astype(np.float32)) for s in ((n,), (n, 3), (n, 3), (n, 7))]
+    params = [p for p in model.parameters() if p.numel() > 0] + ([kw["embedding_a"]] if embed_a else [])
+
+    sig, rgb, _, n_pred, sem = model(x, d, **kw)
+    loss = (sig * ws[0]).sum() + (rgb * ws[1]).sum() + (n_pred * ws[2]).sum() + (sem * ws[3]).sum()
+    fused = torch.autograd.grad(loss, params, allow_unused=True)
+
+    F_ = torch.nn.functional
+    D = torch.float64
+    xn = ((x - model.xyz_min) / (model.xyz_max - model.xyz_min)).contiguous()
+    feat = model.xyz_encoder(xn).to(D)
+    l1, l2 = model.xyz_net[0], model.xyz_net[2]
+    a1 = F_.softplus(feat @ l1.weight.to(D).T + l1.bias.to(D))
+    rsig = F_.softplus(a1 @ l2.weight.to(D).T + l2.bias.to(D))[:, 0]
+    frgb = model.rgb_encoder(xn).to(D)
+    sh = model.dir_encoder((F_.normalize(d, dim=-1) + 1) / 2).to(D)
+    cols = [sh, frgb] + ([kw["embedding_a"].to(D)] if embed_a else [])
+    inp = torch.cat(cols, 1)
+    Kp = model.rgb_net.padded_in
+    if inp.shape[1] < Kp:
+        inp = torch.cat([inp, torch.ones(n, Kp - inp.shape[1], dtype=D, device=DEV)], 1)
+    rrgb = torch.sigmoid(torch.relu(inp @ model.rgb_net.layer_weight(0).to(D).T) @ model.rgb_net.layer_weight(1).to(D).T)[:, :3]
+    hn = torch.relu(frgb @ model.norm_pred_header.layer_weight(0).to(D).T) @ model.norm_pred_header.layer_weight(1).to(D).T
+    rnp = -F_.normalize(hn[:, :3], dim=-1, eps=1e-6)
+    hs = torch.relu(frgb @ model.semantic_header.layer_weight(0).to(D).T) @ model.semantic_header.layer_weight(1).to(D).T
+    rsem = torch.softmax(hs[:, :7], -1)
+    rloss = (rsig * ws[0]).sum() + (rrgb * ws[1]).sum() + (rnp * ws[2]).sum() + (rsem * ws[3]).sum()
+    ref = torch.autograd.grad(rloss, params, allow_unused=True)
+    close(N(sig), N(rsig), 1e-4, 1e-5)
+    close(N(rgb), N(rrgb), 1e-4, 1e-5)
+    names = [n_ for n_, p in model.named_parameters() if p.numel() > 0] + (["embedding_a"] if embed_a else [])
+    for name, a, b in zip(names, fused, ref):
+        assert (a is None) == (b is None), name
+        if a is None:
+            continue
+        a, b = N(a).astype(np.float64), N(b).astype(np.float64)
+        scale = np.abs(b).max() + 1e-12
+        assert np.abs(a - b).max() <= 2e-4 * scale, (name, np.abs(a - b).max(), scale)
+
+
+def test_field_skips_unused_heads(ngp):
+    """No gradient on the normal / semantic outputs -> their headers receive no gradient at all
+    (the reference computes all-zero gradients for them)."""
+    model = _make_model(ngp)
+    g = rng(220)
+    x = T(((g.random((300, 3)) - 0.5) * 0.9).astype(np.float32))
+    d = T(g.normal(size=(300, 3)).astype(np.float32))
+    sig, rgb, *_ = model(x, d)
+    (sig.sum() + rgb.sum()).backward()
+    assert model.norm_pred_header.params.grad is None and model.semantic_header.params.grad is None
+    assert model.rgb_net.params.grad.abs().sum() > 0 and model.xyz_encoder.params.grad.abs().sum() > 0
