@@ -79,7 +79,9 @@ int ngp_clamp_near(float* hits_t, int n_rays, int max_hits, float near_distance,
  * ---------------------------------------------------------------------- */
 int ngp_morton3D(const int32_t* coords, int n, int32_t* indices, void* stream);
 int ngp_morton3D_invert(const int32_t* indices, int n, int32_t* coords, void* stream);
-int ngp_packbits(const float* density_grid, int n_bytes, float threshold,
+/* threshold_dev (device scalar) overrides `threshold` when non-NULL: lets the caller keep
+ * min(mean_density, density_threshold) (networks.py:405-407) on the device, with no .item() sync. */
+int ngp_packbits(const float* density_grid, int n_bytes, float threshold, const float* threshold_dev,
                  uint8_t* density_bitfield, void* stream);
 
 /* NGP.update_density_grid's point generation + EMA, fused (models/networks.py:388-403):

@@ -29,80 +29,130 @@ struct GemmArgs {
     int64_t k_chunk;      // WGRAD: K range per blockIdx.z
     int vecA, vecB;       // 16-byte vector loads legal for the operand
     int accumulate;       // DGRAD: C += result
+    float* bias_grad;     // WGRAD: db[m] += sum_k dz[k][m] (may be null)
 };
+
+// softplus(v) = log(1+e^v) with the hardware exp/log (v_exp_f32 / v_log_f32, ~1e-6 relative):
+// v > 20 -> v (torch's threshold); v < -15 -> e^v (1+e^v would round to 1); else log(1+e^v).
+__device__ __forceinline__ float softplus_fast(float v)
+{
+    const float e = __expf(v);
+    return v > 20.0f ? v : (v < -15.0f ? e : __logf(1.0f + e));
+}
 
 __device__ __forceinline__ float act_fwd(float v, int act)
 {
     switch (act) {
         case NGP_ACT_RELU: return v > 0.0f ? v : 0.0f;
         case NGP_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
-        case NGP_ACT_SOFTPLUS: return v > 20.0f ? v : log1pf(__expf(v));
+        case NGP_ACT_SOFTPLUS: return softplus_fast(v);
         case NGP_ACT_EXP: return __expf(v);
         default: return v;
     }
 }
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 
-// rows x BK tile from a [row][k]-contiguous matrix into dst[k][row] (k-major, ld = LD)
-template <int ROWS, int LD>
-__device__ __forceinline__ void stage_transpose(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows,
-                                                int64_t k0, int64_t kend, bool vec, float* __restrict__ dst)
-{
-    const int t = threadIdx.x;
-    constexpr int PASSES = ROWS >= 64 ? ROWS / 64 : 1;
+// Global -> register fetch and register -> LDS commit are separate so that the fetch of K-tile
+// t+1 is in flight while the MFMAs of tile t run (register double buffering; one LDS buffer).
+
+// rows x BK tile of a [row][k]-contiguous matrix; each thread owns float4 pieces along k
+template <int ROWS>
+struct TileT {
+    static constexpr int KQ = BK / 4;                       // float4 pieces per row
+    static constexpr int RPP = 256 / KQ;                    // rows per pass
+    static constexpr int PASSES = (ROWS + RPP - 1) / RPP;
+    float v[PASSES][4];
+
+    __device__ __forceinline__ void fetch(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t rows,
+                                          int64_t k0, int64_t kend, bool vec)
+    {
+        const int t = threadIdx.x;
 #pragma unroll
-    for (int pass = 0; pass < PASSES; pass++) {
-        const int row = (t >> 2) + pass * 64;
-        if (ROWS < 64 && row >= ROWS) break;
-        const int kq = (t & 3) * 4;
-        const int64_t gr = row0 + row, gk = k0 + kq;
-        float v[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-        if (gr < rows) {
-            const float* p = src + gr * ld + gk;
-            if (vec && gk + 3 < kend) {
-                const float4 q = *reinterpret_cast<const float4*>(p);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-            } else {
+        for (int pass = 0; pass < PASSES; pass++) {
+            const int row = t / KQ + pass * RPP;
+            const int kq = (t % KQ) * 4;
+            const int64_t gr = row0 + row, gk = k0 + kq;
 #pragma unroll
-                for (int j = 0; j < 4; j++) if (gk + j < kend) v[j] = p[j];
+            for (int j = 0; j < 4; j++) v[pass][j] = 0.0f;
+            if (row < ROWS && gr < rows) {
+                const float* p = src + gr * ld + gk;
+                if (vec && gk + 3 < kend) {
+                    const float4 q = *reinterpret_cast<const float4*>(p);
+                    v[pass][0] = q.x; v[pass][1] = q.y; v[pass][2] = q.z; v[pass][3] = q.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if (gk + j < kend) v[pass][j] = p[j];
+                }
             }
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) dst[(kq + j) * LD + row] = v[j];
     }
-}
-
-// BK x COLS tile from a [k][col]-contiguous matrix into dst[k][col]
-template <int COLS, int LD>
-__device__ __forceinline__ void stage_direct(const float* __restrict__ src, int64_t ld, int64_t col0, int64_t cols,
-                                             int64_t k0, int64_t kend, bool vec, float* __restrict__ dst)
-{
-    constexpr int TPR = COLS / 4;          // threads per k-row
-    constexpr int RPP = 256 / TPR;         // k-rows per pass
-    const int t = threadIdx.x;
-    constexpr int PASSES = RPP >= BK ? 1 : BK / RPP;
+    // dst[k][row], k-major with leading dimension LD
+    template <int LD>
+    __device__ __forceinline__ void commit(float* __restrict__ dst) const
+    {
+        const int t = threadIdx.x;
 #pragma unroll
-    for (int pass = 0; pass < PASSES; pass++) {
-        const int kr = t / TPR + pass * RPP;
-        if (RPP > BK && kr >= BK) break;
-        const int c4 = (t % TPR) * 4;
-        const int64_t gk = k0 + kr, gc = col0 + c4;
-        float v[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-        if (gk < kend) {
-            const float* p = src + gk * ld + gc;
-            if (vec && gc + 3 < cols) {
-                const float4 q = *reinterpret_cast<const float4*>(p);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-            } else {
+        for (int pass = 0; pass < PASSES; pass++) {
+            const int row = t / KQ + pass * RPP;
+            const int kq = (t % KQ) * 4;
+            if (row < ROWS) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) if (gc + j < cols) v[j] = p[j];
+                for (int j = 0; j < 4; j++) dst[(kq + j) * LD + row] = v[pass][j];
             }
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) dst[kr * LD + c4 + j] = v[j];
     }
-}
+};
+
+// BK x COLS tile of a [k][col]-contiguous matrix
+template <int COLS>
+struct TileD {
+    static constexpr int TPR = COLS / 4;                    // threads per k-row
+    static constexpr int RPP = 256 / TPR;                   // k-rows per pass
+    static constexpr int PASSES = (BK + RPP - 1) / RPP;
+    float v[PASSES][4];
+
+    __device__ __forceinline__ void fetch(const float* __restrict__ src, int64_t ld, int64_t col0, int64_t cols,
+                                          int64_t k0, int64_t kend, bool vec)
+    {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int pass = 0; pass < PASSES; pass++) {
+            const int kr = t / TPR + pass * RPP;
+            const int c4 = (t % TPR) * 4;
+            const int64_t gk = k0 + kr, gc = col0 + c4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[pass][j] = 0.0f;
+            if (kr < BK && gk < kend) {
+                const float* p = src + gk * ld + gc;
+                if (vec && gc + 3 < cols) {
+                    const float4 q = *reinterpret_cast<const float4*>(p);
+                    v[pass][0] = q.x; v[pass][1] = q.y; v[pass][2] = q.z; v[pass][3] = q.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if (gc + j < cols) v[pass][j] = p[j];
+                }
+            }
+        }
+    }
+    template <int LD>
+    __device__ __forceinline__ void commit(float* __restrict__ dst) const
+    {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int pass = 0; pass < PASSES; pass++) {
+            const int kr = t / TPR + pass * RPP;
+            const int c4 = (t % TPR) * 4;
+            if (kr < BK) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) dst[kr * LD + c4 + j] = v[pass][j];
+            }
+        }
+    }
+};
+
+template <bool TRANSPOSED, int EXT> struct TileSel { typedef TileT<EXT> type; };
+template <int EXT> struct TileSel<false, EXT> { typedef TileD<EXT> type; };
 
 template <int MODE, int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs p)
@@ -130,12 +180,27 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs p)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
 
+    // A is [m][k] (transposed staging) except for WGRAD where it is dz [k][m];
+    // B is W [n][k] for FWD (transposed staging), W [k][n] / x [k][n] otherwise.
+    typename TileSel<MODE != MODE_WGRAD, BM>::type ta;
+    typename TileSel<MODE == MODE_FWD, BN>::type tb;
+    float bias_acc = 0.0f; // WGRAD: column sums of dz for db (blockIdx.y == 0 only)
+    const bool want_db = MODE == MODE_WGRAD && p.bias_grad != nullptr && blockIdx.y == 0;
+
+    ta.fetch(p.A, p.lda, m0, p.M, kbeg, kend, p.vecA);
+    tb.fetch(p.B, p.ldb, n0, p.N, kbeg, kend, p.vecB);
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        if (MODE == MODE_WGRAD) stage_direct<BM, LDA>(p.A, p.lda, m0, p.M, k0, kend, p.vecA, As);
-        else stage_transpose<BM, LDA>(p.A, p.lda, m0, p.M, k0, kend, p.vecA, As);
-        if (MODE == MODE_FWD) stage_transpose<BN, LDB>(p.B, p.ldb, n0, p.N, k0, kend, p.vecB, Bs);
-        else stage_direct<BN, LDB>(p.B, p.ldb, n0, p.N, k0, kend, p.vecB, Bs);
+        ta.template commit<LDA>(As);
+        tb.template commit<LDB>(Bs);
         __syncthreads();
+        if (k0 + BK < kend) {
+            ta.fetch(p.A, p.lda, m0, p.M, k0 + BK, kend, p.vecA);
+            tb.fetch(p.B, p.ldb, n0, p.N, k0 + BK, kend, p.vecB);
+        }
+        if (want_db && threadIdx.x < BM) {
+#pragma unroll
+            for (int k = 0; k < BK; k++) bias_acc += As[k * LDA + threadIdx.x];
+        }
 #pragma unroll
         for (int s = 0; s < BK / 2; s++) {
             float a[TM], b[TN];
@@ -151,6 +216,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs p)
         }
         __syncthreads();
     }
+    if (want_db && threadIdx.x < BM && m0 + threadIdx.x < p.M) atomicAdd(p.bias_grad + m0 + threadIdx.x, bias_acc);
 
 #pragma unroll
     for (int tm = 0; tm < TM; tm++)
@@ -179,30 +245,64 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs p)
 }
 
 // ---------------------------------------------------------------- skinny layers (n_out <= 4)
-// forward: one half-wave per sample row, lanes stride over k, dot product by xor-shuffle
-__global__ void skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int64_t ldw,
-                                  const float* __restrict__ b, int64_t n, int n_in, int n_out, int act,
-                                  float* __restrict__ y, int64_t ldy, float* __restrict__ z_pre)
+// forward: one half-wave per sample row, each lane owns float4 pieces of the row (16-byte loads),
+// four rows per half-wave in flight, dot products reduced by xor-shuffles.
+__global__ void __launch_bounds__(256) skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ b, int64_t n, int n_in, int n_out,
+                                                         int act, float* __restrict__ y, int64_t ldy,
+                                                         float* __restrict__ z_pre, int vec)
 {
-    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     const int lane = threadIdx.x & 31;
-    if (row >= n) return;
-    float acc[4] = { 0, 0, 0, 0 };
-    for (int k = lane; k < n_in; k += 32) {
-        const float xv = x[row * ldx + k];
+    const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int64_t row0 = hw * 4;
+    if (row0 >= n) return;
+    float acc[4][4];
 #pragma unroll
-        for (int o = 0; o < 4; o++) if (o < n_out) acc[o] = fmaf(xv, W[o * ldw + k], acc[o]);
-    }
+    for (int u = 0; u < 4; u++)
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
-        if (o >= n_out) break;
-        float v = half_sum(acc[o]);
-        if (lane == 0) {
-            if (b) v += b[o];
-            if (z_pre) z_pre[row * n_out + o] = v;
-            y[row * ldy + o] = act_fwd(v, act);
+        for (int o = 0; o < 4; o++) acc[u][o] = 0.0f;
+    if (vec) {
+        for (int k = lane * 4; k < n_in; k += 128) {
+            float4 xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t r = row0 + u < n ? row0 + u : n - 1;
+                xv[u] = *reinterpret_cast<const float4*>(x + r * ldx + k);
+            }
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                if (o < n_out) {
+                    const float4 w = *reinterpret_cast<const float4*>(W + o * ldw + k);
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        acc[u][o] += xv[u].x * w.x + xv[u].y * w.y + xv[u].z * w.z + xv[u].w * w.w;
+                }
+            }
+        }
+    } else {
+        for (int k = lane; k < n_in; k += 32) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t r = row0 + u < n ? row0 + u : n - 1;
+                const float xv = x[r * ldx + k];
+#pragma unroll
+                for (int o = 0; o < 4; o++) if (o < n_out) acc[u][o] = fmaf(xv, W[o * ldw + k], acc[u][o]);
+            }
         }
     }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            if (o >= n_out) continue;
+            float v = half_sum(acc[u][o]);
+            if (lane == 0 && row0 + u < n) {
+                if (b) v += b[o];
+                if (z_pre) z_pre[(row0 + u) * n_out + o] = v;
+                y[(row0 + u) * ldy + o] = act_fwd(v, act);
+            }
+        }
 }
 
 __global__ void skinny_dgrad_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ W, int64_t ldw,
@@ -218,22 +318,66 @@ __global__ void skinny_dgrad_kernel(const float* __restrict__ dz, int64_t lddz, 
     dx[row * lddx + k] = v;
 }
 
-// dW[o][k] += sum_rows dz[row][o]*x[row][k]; one block per chunk of rows, thread = k column
-__global__ void skinny_wgrad_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ x, int64_t ldx,
-                                    int64_t n, int n_in, int n_out, int rows_per_block, float* __restrict__ dW,
-                                    int64_t ldw)
+// dW[o][k] += sum_rows dz[row][o]*x[row][k] (n_out <= 4), db[o] += sum_rows dz[row][o].
+// 256 threads = (256/CW) row lanes x CW column lanes; rows are walked four at a time so that four
+// independent x loads are in flight per thread; LDS tree over the row lanes; one atomic per output.
+__global__ void __launch_bounds__(256) skinny_wgrad_kernel(const float* __restrict__ dz, int64_t lddz,
+                                                           const float* __restrict__ x, int64_t ldx, int64_t n,
+                                                           int n_in, int n_out, int cw, int rows_per_block,
+                                                           float* __restrict__ dW, int64_t ldw, float* __restrict__ db)
 {
+    __shared__ float part[4][256];
+    const int k = threadIdx.x % cw, rl = threadIdx.x / cw, nrl = 256 / cw;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
-    for (int k = threadIdx.x; k < n_in; k += blockDim.x) {
-        float acc[4] = { 0, 0, 0, 0 };
-        for (int64_t r = r0; r < r1; r++) {
-            const float xv = x[r * ldx + k];
+    float acc[4] = { 0, 0, 0, 0 }, bsum[4] = { 0, 0, 0, 0 };
+    if (k < n_in) {
+        for (int64_t r = r0 + rl; r < r1; r += 4 * nrl) {
+            float xv[4], dv[4][4];
 #pragma unroll
-            for (int o = 0; o < 4; o++) if (o < n_out) acc[o] = fmaf(dz[r * lddz + o], xv, acc[o]);
+            for (int u = 0; u < 4; u++) {
+                const int64_t rr = r + u * nrl;
+                const bool ok = rr < r1;
+                xv[u] = ok ? x[rr * ldx + k] : 0.0f;
+#pragma unroll
+                for (int o = 0; o < 4; o++) dv[u][o] = (ok && o < n_out) ? dz[rr * lddz + o] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int o = 0; o < 4; o++) { acc[o] = fmaf(dv[u][o], xv[u], acc[o]); bsum[o] += dv[u][o]; }
         }
+    }
 #pragma unroll
-        for (int o = 0; o < 4; o++) if (o < n_out) atomicAdd(dW + o * ldw + k, acc[o]);
+    for (int o = 0; o < 4; o++) part[o][threadIdx.x] = acc[o];
+    __syncthreads();
+    for (int s = nrl / 2; s > 0; s >>= 1) {
+        if (rl < s) {
+#pragma unroll
+            for (int o = 0; o < 4; o++) part[o][threadIdx.x] += part[o][threadIdx.x + s * cw];
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && k < n_in) {
+#pragma unroll
+        for (int o = 0; o < 4; o++) if (o < n_out) atomicAdd(dW + o * ldw + k, part[o][threadIdx.x]);
+    }
+    if (db) { // column 0's lanes hold the dz sums: reduce them over the row lanes as well
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 4; o++) part[o][threadIdx.x] = (k == 0) ? bsum[o] : 0.0f;
+        __syncthreads();
+        for (int s = nrl / 2; s > 0; s >>= 1) {
+            if (rl < s && k == 0) {
+#pragma unroll
+                for (int o = 0; o < 4; o++) part[o][threadIdx.x] += part[o][threadIdx.x + s * cw];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int o = 0; o < 4; o++) if (o < n_out) atomicAdd(db + o, part[o][0]);
+        }
     }
 }
 
@@ -304,24 +448,53 @@ __global__ void __launch_bounds__(256) mlp_hidden_bwd_kernel(const float* __rest
                                                              float* __restrict__ dz2, int64_t lddz2,
                                                              float* __restrict__ dz1, int64_t lddz1)
 {
-    const int rows_per_block = 256 / H;   // H is 32, 64 or 128
-    const int j = threadIdx.x % H;
-    const int rsub = threadIdx.x / H;
-    float w[OMAX];
+    // lane = (row lane, 4 consecutive hidden columns): 16-byte loads/stores of hidden / dz1
+    const int lpr = H / 4;                 // lanes per row
+    const int rows_per_block = 256 / lpr;
+    const int j4 = (threadIdx.x % lpr) * 4;
+    const int rsub = threadIdx.x / lpr;
+    float w[OMAX][4];
 #pragma unroll
-    for (int o = 0; o < OMAX; o++) w[o] = o < n_out ? W2[o * ldw2 + j] : 0.0f;
-    for (int64_t row = (int64_t)blockIdx.x * rows_per_block + rsub; row < n; row += (int64_t)gridDim.x * rows_per_block) {
-        float acc = 0.0f;
+    for (int o = 0; o < OMAX; o++)
 #pragma unroll
-        for (int o = 0; o < OMAX; o++) {
-            if (o < n_out) {
-                const float g = dOut ? dOut[row * lddo + o] : 1.0f;
-                const float d = g * act_grad_from_output(out[row * ldo + o], act2);
-                acc = fmaf(d, w[o], acc);
-                if (dz2 && j == o) dz2[row * lddz2 + o] = d;
+        for (int c = 0; c < 4; c++) w[o][c] = o < n_out ? W2[o * ldw2 + j4 + c] : 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * rows_per_block;
+    for (int64_t row0 = (int64_t)blockIdx.x * rows_per_block + rsub; row0 < n; row0 += 2 * stride) {
+        float4 hv[2];
+        float acc[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int64_t row = row0 + u * stride;
+            hv[u] = row < n ? *reinterpret_cast<const float4*>(hidden + row * ldh + j4) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[u][c] = 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int64_t row = row0 + u * stride;
+            if (row >= n) continue;
+#pragma unroll
+            for (int o = 0; o < OMAX; o++) {
+                if (o < n_out) {
+                    const float g = dOut ? dOut[row * lddo + o] : 1.0f;
+                    const float d = g * act_grad_from_output(out[row * ldo + o], act2);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[u][c] = fmaf(d, w[o][c], acc[u][c]);
+                    if (dz2 && j4 == 0) dz2[row * lddz2 + o] = d;
+                }
             }
         }
-        dz1[row * lddz1 + j] = acc * act_grad_from_output(hidden[row * ldh + j], act1);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int64_t row = row0 + u * stride;
+            if (row >= n) continue;
+            float4 r;
+            r.x = acc[u][0] * act_grad_from_output(hv[u].x, act1);
+            r.y = acc[u][1] * act_grad_from_output(hv[u].y, act1);
+            r.z = acc[u][2] * act_grad_from_output(hv[u].z, act1);
+            r.w = acc[u][3] * act_grad_from_output(hv[u].w, act1);
+            *reinterpret_cast<float4*>(dz1 + row * lddz1 + j4) = r;
+        }
     }
 }
 
@@ -401,8 +574,9 @@ int ngp_linear_fwd(const float* x, int64_t ldx, const float* W, int64_t ldw, con
     if (!x || !W || !y) return NGP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (n_out <= 4) {
-        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(ngp_blocks(n * 32, 256)), dim3(256), 0, st, x, ldx, W, ldw, b, n,
-                           n_in, n_out, activation, y, ldy, z_pre);
+        const int vec = aligned16(x) && aligned16(W) && (ldx % 4 == 0) && (ldw % 4 == 0) && (n_in % 4 == 0);
+        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(ngp_blocks((n + 3) / 4 * 32, 256)), dim3(256), 0, st, x, ldx, W, ldw,
+                           b, n, n_in, n_out, activation, y, ldy, z_pre, vec);
         return ngp_check_launch();
     }
     GemmArgs p{};
@@ -452,22 +626,18 @@ int ngp_linear_bwd_weight(const float* dz, int64_t lddz, const float* x, int64_t
     if (n == 0) return NGP_OK;
     if (!dz || !x || !dW) return NGP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (db) {
-        if (n_out > 128) return NGP_EINVAL;
-        int cw = 1;
-        while (cw < n_out) cw <<= 1;
-        const int rpb = 4096;
-        hipLaunchKernelGGL(colsum_kernel, dim3(ngp_blocks(n, rpb)), dim3(256), 0, st, dz, lddz, n, n_out, cw, rpb, db);
-    }
     if (n_out <= 4) {
+        if (n_in > 256) return NGP_EINVAL;
+        int cw = 1;
+        while (cw < n_in) cw <<= 1;
         const int rpb = 512;
-        hipLaunchKernelGGL(skinny_wgrad_kernel, dim3(ngp_blocks(n, rpb)), dim3(n_in >= 256 ? 256 : (n_in >= 128 ? 128 : 64)),
-                           0, st, dz, lddz, x, ldx, n, n_in, n_out, rpb, dW, ldw);
+        hipLaunchKernelGGL(skinny_wgrad_kernel, dim3(ngp_blocks(n, rpb)), dim3(256), 0, st, dz, lddz, x, ldx, n, n_in,
+                           n_out, cw, rpb, dW, ldw, db);
         return ngp_check_launch();
     }
     GemmArgs p{};
     p.A = dz; p.lda = lddz; p.B = x; p.ldb = ldx; p.C = dW; p.ldc = ldw;
-    p.M = n_out; p.N = n_in; p.K = n; p.act = 0;
+    p.M = n_out; p.N = n_in; p.K = n; p.act = 0; p.bias_grad = db;
     p.vecA = aligned16(dz) && (lddz % 4 == 0); p.vecB = aligned16(x) && (ldx % 4 == 0);
     // split the sample dimension so that ~1024 workgroups are in flight
     const bool big_m = n_out > 32, big_n = n_in > 32;
@@ -514,7 +684,8 @@ int ngp_mlp_hidden_bwd(const float* dOut, int64_t lddo, const float* out, int64_
     if (n < 0 || n_out < 1 || n_out > 16 || !(H == 32 || H == 64 || H == 128)) return NGP_EINVAL;
     if (n == 0) return NGP_OK;
     if (!out || !W2 || !hidden || !dz1) return NGP_EINVAL;
-    const int rows_per_block = 256 / H;
+    if (((uintptr_t)hidden & 15) || ((uintptr_t)dz1 & 15) || (ldh % 4) || (lddz1 % 4)) return NGP_EINVAL;
+    const int rows_per_block = 256 / (H / 4);
     int64_t blocks = (n + rows_per_block - 1) / rows_per_block;
     if (blocks > 8192) blocks = 8192;
     hipStream_t st = (hipStream_t)stream;

@@ -125,10 +125,12 @@ __global__ void morton_invert_kernel(const int32_t* __restrict__ idx, int n, int
 }
 
 // one lane per output byte; the 8 floats of a byte are two 16-byte loads
-__global__ void packbits_kernel(const float4* __restrict__ grid, int n_bytes, float thr, uint8_t* __restrict__ bits)
+__global__ void packbits_kernel(const float4* __restrict__ grid, int n_bytes, float thr_host,
+                                const float* __restrict__ thr_dev, uint8_t* __restrict__ bits)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_bytes) return;
+    const float thr = thr_dev ? *thr_dev : thr_host;
     const float4 a = grid[2 * (size_t)n], b = grid[2 * (size_t)n + 1];
     uint32_t m = 0;
     m |= (a.x > thr) ? 1u : 0u;   m |= (a.y > thr) ? 2u : 0u;
@@ -417,13 +419,14 @@ int ngp_morton3D_invert(const int32_t* indices, int n, int32_t* coords, void* st
     return ngp_check_launch();
 }
 
-int ngp_packbits(const float* density_grid, int n_bytes, float threshold, uint8_t* density_bitfield, void* stream)
+int ngp_packbits(const float* density_grid, int n_bytes, float threshold, const float* threshold_dev,
+                 uint8_t* density_bitfield, void* stream)
 {
     if (n_bytes < 0) return NGP_EINVAL;
     if (n_bytes == 0) return NGP_OK;
     if (!density_grid || !density_bitfield || ((uintptr_t)density_grid & 15)) return NGP_EINVAL;
     hipLaunchKernelGGL(packbits_kernel, dim3(ngp_blocks(n_bytes, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)density_grid, n_bytes, threshold, density_bitfield);
+                       (const float4*)density_grid, n_bytes, threshold, threshold_dev, density_bitfield);
     return ngp_check_launch();
 }
 

@@ -421,10 +421,17 @@ class NGP(nn.Module):
             coords1 = torch.randint(self.grid_size, (M, 3), dtype=torch.int32, device=self.density_grid.device,
                                     generator=gen)
             indices1 = vren.morton3D(coords1).long()
-            indices2 = torch.nonzero(self.density_grid[c] > density_threshold)[:, 0]
-            if len(indices2) > 0:
-                rand_idx = torch.randint(len(indices2), (M,), device=self.density_grid.device, generator=gen)
-                indices2 = indices2[rand_idx]
+            # M random occupied cells without a host round trip (the reference's nonzero() +
+            # randint(len) syncs): rank r ~ U[0, n_occ) is mapped to the r-th occupied cell through
+            # the running count of the occupancy mask.  With no occupied cell at all the reference
+            # samples none; here those M draws fall back onto the uniform cells (same coverage).
+            occ = self.density_grid[c] > density_threshold
+            csum = torch.cumsum(occ, 0, dtype=torch.int32)
+            n_occ = csum[-1]
+            u = torch.rand(M, device=occ.device, generator=gen)
+            rank = torch.clamp((u * n_occ).to(torch.int32), max=n_occ - 1) + 1
+            pos = torch.searchsorted(csum, rank.clamp(min=1), right=False)
+            indices2 = torch.where(n_occ > 0, pos.clamp(max=occ.numel() - 1), indices1)
             coords2 = vren.morton3D_invert(indices2.int())
             cells += [(torch.cat([indices1, indices2]), torch.cat([coords1, coords2]))]
         return cells
@@ -479,8 +486,11 @@ class NGP(nn.Module):
                                             torch.maximum(self.density_grid * decay_t, density_grid_tmp))
         else:
             call("density_grid_ema", self.density_grid, density_grid_tmp, self.density_grid.numel(), float(decay))
-        mean_density = self.density_grid[self.density_grid > 0].mean().item()
-        vren.packbits(self.density_grid.view(-1), min(mean_density, density_threshold), self.density_bitfield)
+        # threshold = min(mean of the positive cells, density_threshold), kept on the device
+        pos = self.density_grid > 0
+        mean_density = (self.density_grid * pos).sum() / pos.sum().clamp(min=1)
+        thr = torch.clamp(mean_density, max=density_threshold).reshape(1)
+        call("packbits", self.density_grid.view(-1), self.density_bitfield.shape[0], 0.0, thr, self.density_bitfield)
 
     def uniform_sample(self, resolution=128):
         half_grid_size = self.scale / resolution

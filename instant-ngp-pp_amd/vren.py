@@ -61,7 +61,7 @@ def morton3D_invert(indices):
 def packbits(density_grid, density_threshold, density_bitfield):
     """binding.cpp:90-101: writes density_bitfield in place, returns None"""
     _chk(density_grid=density_grid, density_bitfield=density_bitfield)
-    call("packbits", density_grid, density_bitfield.shape[0], float(density_threshold), density_bitfield)
+    call("packbits", density_grid, density_bitfield.shape[0], float(density_threshold), None, density_bitfield)
 
 
 def _march_train(rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, noise, grid_size,
