@@ -12,10 +12,11 @@ MI355X-specific structure:
     coefficient and zeroes the gradient), two large RCCL all-reduces instead of per-tensor ones;
   * the hash-grid scatter kernels accumulate straight into the flat gradient buffer (no
     zeros_like + add pass over 800 MB);
-  * with world_size > 1 the rgb-table bucket (77 % of the bytes) is all-reduced on RCCL's stream
-    as soon as its scatter-add is enqueued, overlapping the density-path backward; the second
-    bucket overlaps the host-side work of the next step.  The clip norm needs every reduced
-    gradient, so the Adam launch waits for both.
+  * with world_size > 1 the optimizer is sharded (ZeRO-1 style): gradients are reduce-scattered
+    over RCCL (the rgb-table bucket, 77 % of the bytes, as soon as its scatter-add is enqueued, so
+    it overlaps the density-path backward), every rank runs clip + Adam on its 1/N slice only
+    (Adam's 6.4 GB/step of HBM traffic becomes 6.4/N GB), and the updated parameter slices are
+    all-gathered.  Same bytes on xGMI as an all-reduce, 1/N of the optimizer time and state.
 """
 import math
 
@@ -30,8 +31,15 @@ _f32 = torch.float32
 
 
 class GradBuckets:
-    """Sum-all-reduce of contiguous slices of one flat gradient buffer (device agnostic: the
-    gloo CPU tests drive this class directly)."""
+    """Collectives over contiguous buckets of the flat gradient / parameter buffers (device
+    agnostic: the gloo CPU tests drive this class directly).
+
+    all-reduce mode   : reduce_bucket(i) sums bucket i over the ranks (async), wait() joins.
+    sharded mode      : reduce_scatter_bucket(i) leaves rank r with the summed slice r of bucket i
+                        (in place, RCCL reduce-scatter), all_gather_bucket(i, flat_param) publishes
+                        each rank's updated parameter slice to everyone (in place all-gather).
+    Buckets must be a multiple of world*4 elements long in sharded mode (the trainer pads).
+    """
 
     def __init__(self, flat_grad, boundaries, group=None):
         self.flat = flat_grad
@@ -43,11 +51,48 @@ class GradBuckets:
     def world(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    @property
+    def rank(self):
+        return dist.get_rank(self.group) if dist.is_available() and dist.is_initialized() else 0
+
+    def _native_rs(self):
+        return dist.get_backend(self.group) == "nccl"
+
+    def shard_range(self, i):
+        lo, hi = self.bounds[i], self.bounds[i + 1]
+        s = (hi - lo) // self.world
+        return lo + self.rank * s, lo + (self.rank + 1) * s
+
     def reduce_bucket(self, i):
         if self.world == 1:
             return
         lo, hi = self.bounds[i], self.bounds[i + 1]
         self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def reduce_scatter_bucket(self, i):
+        if self.world == 1:
+            return
+        lo, hi = self.bounds[i], self.bounds[i + 1]
+        if self._native_rs():
+            a, b = self.shard_range(i)
+            self.works.append(dist.reduce_scatter_tensor(self.flat[a:b], self.flat[lo:hi], op=dist.ReduceOp.SUM,
+                                                         group=self.group, async_op=True))
+        else:  # gloo has no reduce-scatter: all-reduce, the owner simply uses its slice
+            self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                              async_op=True))
+
+    def all_gather_bucket(self, i, flat_param):
+        if self.world == 1:
+            return
+        lo, hi = self.bounds[i], self.bounds[i + 1]
+        a, b = self.shard_range(i)
+        if self._native_rs():
+            self.works.append(dist.all_gather_into_tensor(flat_param[lo:hi], flat_param[a:b], group=self.group,
+                                                          async_op=True))
+        else:
+            s = (hi - lo) // self.world
+            views = [flat_param[lo + r * s: lo + (r + 1) * s] for r in range(self.world)]
+            self.works.append(dist.all_gather(views, flat_param[a:b].clone(), group=self.group, async_op=True))
 
     def wait(self):
         for w in self.works:
@@ -86,13 +131,18 @@ class NGPTrainer:
         order = {"rgb_encoder.params": 0, "xyz_encoder.params": 1}
         named.sort(key=lambda np_: order.get(np_[0], 2))
         self.names = [n for n, _ in named]
-        sizes = [(p.numel() + 3) // 4 * 4 for _, p in named]  # keep every slice 16-byte aligned
+        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        quantum = 4 * world   # every slice 16-byte aligned; every bucket divisible by the world size
+        sizes = [(p.numel() + 3) // 4 * 4 for _, p in named]
+        if named[0][0] == "rgb_encoder.params":           # bucket 0 = the colour table alone
+            sizes[0] = (sizes[0] + quantum - 1) // quantum * quantum
+        rest = sum(sizes[1:]) if named[0][0] == "rgb_encoder.params" else sum(sizes)
+        sizes[-1] += (quantum - rest % quantum) % quantum
         total = sum(sizes)
         dev = named[0][1].device
+        self.sharded = world > 1
         self.flat_param = torch.zeros(total, dtype=_f32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=_f32, device=dev)
-        self.exp_avg = torch.zeros(total, dtype=_f32, device=dev)
-        self.exp_avg_sq = torch.zeros(total, dtype=_f32, device=dev)
         self.scalars = torch.zeros(2, dtype=_f32, device=dev)  # [sum of squares, clip coefficient]
         off = 0
         self.slices = {}
@@ -104,16 +154,26 @@ class NGPTrainer:
             self.slices[n] = (off, p.numel())
             off += sz
         # bucket 0 = rgb table, bucket 1 = everything else
-        b0 = self.slices["rgb_encoder.params"][1] if "rgb_encoder.params" in self.slices else 0
-        b0 = (b0 + 3) // 4 * 4
-        self.buckets = GradBuckets(self.flat_grad, [0, b0, total], group=self.group)
+        b0 = sizes[0] if named[0][0] == "rgb_encoder.params" else 0
+        self.buckets = GradBuckets(self.flat_grad, [0, b0, total] if b0 else [0, total], group=self.group)
+        # Adam state: whole buffer on one GPU; with N ranks each rank keeps (and updates) only its
+        # 1/N slice of every bucket — reduce-scatter gradients, Adam on the slice, all-gather params
+        if self.sharded:
+            self.shards = [self.buckets.shard_range(i) for i in range(len(self.buckets.bounds) - 1)]
+            self.exp_avg = [torch.zeros(b - a, dtype=_f32, device=dev) for a, b in self.shards]
+            self.exp_avg_sq = [torch.zeros(b - a, dtype=_f32, device=dev) for a, b in self.shards]
+        else:
+            self.exp_avg = torch.zeros(total, dtype=_f32, device=dev)
+            self.exp_avg_sq = torch.zeros(total, dtype=_f32, device=dev)
         # scatter kernels accumulate directly into the flat gradient (see tinycudann._GridFwd)
         for enc_name in ("rgb_encoder", "xyz_encoder"):
             enc = getattr(self.model, enc_name, None)
             if enc is not None:
                 enc.grad_buffer = enc.params.grad
-        if hasattr(self.model, "rgb_encoder"):
-            self.model.rgb_encoder.on_grad_ready = lambda: self.buckets.reduce_bucket(0)
+        # bucket 0's reduce-scatter is fired from the colour encoder's backward (overlaps the rest)
+        self.hooked0 = bool(hasattr(self.model, "rgb_encoder") and self.sharded and b0)
+        if self.hooked0:
+            self.model.rgb_encoder.on_grad_ready = lambda: self.buckets.reduce_scatter_bucket(0)
 
     # ------------------------------------------------------------------ schedule
     def lr_at(self, epoch):
@@ -140,17 +200,33 @@ class NGPTrainer:
 
     def optimizer_step(self):
         world = self.buckets.world
-        self.buckets.reduce_bucket(1)
-        self.buckets.wait()
-        n = self.flat_grad.numel()
-        self.scalars.zero_()
-        call("sumsq", self.flat_grad, n, self.scalars[0:1])
-        call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0 / world, self.scalars[1:2])
         self.global_step += 1
         # lr of the epoch this step belongs to (the scheduler ticks at epoch boundaries)
         lr = self.lr_at(min((self.global_step - 1) // self.steps_per_epoch, self.num_epochs))
-        call("adam_step", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, n, float(lr), 0.9, 0.999,
-             1e-8, 0.0, self.global_step, self.scalars[1:2], 1)
+        self.scalars.zero_()
+        if not self.sharded:
+            n = self.flat_grad.numel()
+            call("sumsq", self.flat_grad, n, self.scalars[0:1])
+            call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2])
+            call("adam_step", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, n, float(lr), 0.9, 0.999,
+                 1e-8, 0.0, self.global_step, self.scalars[1:2], 1)
+            return
+        # sharded: bucket 0's reduce-scatter was issued from the colour encoder's backward
+        nb = len(self.buckets.bounds) - 1
+        for i in range(1 if self.hooked0 else 0, nb):
+            self.buckets.reduce_scatter_bucket(i)
+        self.buckets.wait()
+        for (a, b) in self.shards:          # global grad norm = sqrt(sum over ranks of shard sums)
+            call("sumsq", self.flat_grad[a:b], b - a, self.scalars[0:1])
+        dist.all_reduce(self.scalars[0:1], op=dist.ReduceOp.SUM, group=self.group)
+        call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0 / world, self.scalars[1:2])
+        for i, (a, b) in enumerate(self.shards):
+            call("adam_step", self.flat_param[a:b], self.flat_grad[a:b], self.exp_avg[i], self.exp_avg_sq[i], b - a,
+                 float(lr), 0.9, 0.999, 1e-8, 0.0, self.global_step, self.scalars[1:2], 0)
+        for i in range(nb):
+            self.buckets.all_gather_bucket(i, self.flat_param)
+        self.flat_grad.zero_()              # the other ranks' slices hold partial sums: start clean
+        self.buckets.wait()
 
     # ------------------------------------------------------------------ multi-GPU helpers
     def broadcast_state(self, src=0):

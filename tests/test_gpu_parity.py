@@ -570,3 +570,34 @@ def test_field_skips_unused_heads(ngp):
     (sig.sum() + rgb.sum()).backward()
     assert model.norm_pred_header.params.grad is None and model.semantic_header.params.grad is None
     assert model.rgb_net.params.grad.abs().sum() > 0 and model.xyz_encoder.params.grad.abs().sum() > 0
+
+
+# ---------------------------------------------------------------------------- trainer
+def test_trainer_steps_reduce_loss(ngp):
+    """A few steps of the full schedule (grid update, render, NeRFLoss, backward, clip + fused Adam
+    on the flat parameter buffer) on the synthetic scene lower the loss and keep parameters finite."""
+    from ngp_amd.synthetic import LegoProxy
+    from ngp_amd.trainer import NGPTrainer
+    torch.manual_seed(3)
+    model = ngp.networks.NGP(scale=0.5).to(DEV)
+    G = model.grid_size
+    model.register_buffer("density_grid", torch.zeros(model.cascades, G ** 3, device=DEV))
+    coords = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=DEV)] * 3, indexing="ij"), -1)
+    model.register_buffer("grid_coords", coords.reshape(-1, 3).contiguous())
+    scene = LegoProxy(n_images=20, img_wh=(200, 200), device=DEV)
+    tr = NGPTrainer(model, lr=1e-2)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    losses = []
+    for i in range(40):
+        img, pix = scene.sample_batch(1024, generator=gen)
+        o, d = scene.rays(img, pix)
+        gt, _ = scene.ground_truth(o, d, n_quad=128)
+        loss, res = tr.step(o, d, gt)
+        losses.append(float(loss))
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-5:]) < 0.5 * np.mean(losses[:5])
+    assert torch.isfinite(tr.flat_param).all()
+    assert not tr.flat_grad.any()              # the fused Adam zeroes the gradient buffer
+    assert tr.global_step == 40
+    # parameters are views of the flat buffer (state-dict keys stay the reference's)
+    assert model.rgb_encoder.params.data_ptr() == tr.flat_param.data_ptr()
