@@ -243,6 +243,77 @@ __global__ void __launch_bounds__(256) grid_bwd_param_merge_kernel(GridMeta meta
     if (have) flush();
 }
 
+// Variant of the run-merging scatter in which 16 lanes serve one level: lane = (level, x-corner,
+// feature).  The two x-neighbours of a corner pair are adjacent table rows whenever the base
+// index is even (dense levels: idx = x + ...; hashed levels: x enters the hash as x ^ ..., so
+// x|1 flips only bit 0), and the atomic unit works on 64-byte blocks: issuing both rows from
+// the same wave-instruction lets one memory-side request carry 64 B instead of 32 B.
+template <int F, int CHUNK>
+__global__ void __launch_bounds__(256) grid_bwd_param_merge2_kernel(GridMeta meta, const float* __restrict__ x,
+                                                                    const float* __restrict__ dL_dy, int64_t lddy,
+                                                                    int64_t n, float* __restrict__ dtable)
+{
+    constexpr int LV = 64 / (2 * F);  // levels per wave
+    constexpr int SUB = 8;
+    const uint32_t L = meta.n_levels;
+    const uint32_t waves_per_chunk = (L + LV - 1) / LV;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t chunk = __builtin_amdgcn_readfirstlane((int)(wave_global / waves_per_chunk));
+    const uint32_t lg = __builtin_amdgcn_readfirstlane((int)(wave_global % waves_per_chunk));
+    const int lane = threadIdx.x & 63;
+    const uint32_t level = lg * LV + lane / (2 * F);
+    const uint32_t xb = (lane / F) & 1;
+    const int f = lane % F;
+    const int64_t s0 = chunk * CHUNK;
+    if (s0 >= n) return;
+    const int64_t s1 = s0 + CHUNK < n ? s0 + CHUNK : n;
+    const bool active = level < L;
+    const LevelInfo li = level_info(meta, active ? level : 0);
+    const size_t ld = (size_t)lddy;
+
+    float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    uint32_t b0 = 0, b1 = 0, b2 = 0;
+    bool have = false;
+
+    auto flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (acc[k] != 0.0f) {
+                const uint32_t row = row_index(li, b0 + xb, b1 + (k & 1), b2 + ((k >> 1) & 1));
+                atomicAdd(dtable + (size_t)row * F + f, acc[k]);
+            }
+            acc[k] = 0.0f;
+        }
+    };
+
+    for (int64_t sb = s0; sb < s1; sb += SUB) {
+        float g[SUB], px[SUB], py[SUB], pz[SUB];
+#pragma unroll
+        for (int j = 0; j < SUB; j++) {
+            const int64_t s = sb + j < s1 ? sb + j : s1 - 1;
+            g[j] = active ? dL_dy[(size_t)s * ld + level * F + f] : 0.0f;
+            px[j] = x[3 * s]; py[j] = x[3 * s + 1]; pz[j] = x[3 * s + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < SUB; j++) {
+            if (sb + j >= s1) break;
+            const float p0 = fmaf(li.scale, px[j], 0.5f), p1 = fmaf(li.scale, py[j], 0.5f), p2 = fmaf(li.scale, pz[j], 0.5f);
+            const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+            const uint32_t g0 = (uint32_t)(int)f0, g1 = (uint32_t)(int)f1, g2 = (uint32_t)(int)f2;
+            const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+            if (!(have && g0 == b0 && g1 == b1 && g2 == b2)) {
+                if (have) flush();
+                b0 = g0; b1 = g1; b2 = g2; have = true;
+            }
+            const float xw = (xb ? w0 : 1 - w0) * g[j];
+            const float y0 = 1 - w1, y1 = w1, z0 = 1 - w2, z1 = w2;
+            acc[0] = fmaf(xw * y0, z0, acc[0]); acc[1] = fmaf(xw * y1, z0, acc[1]);
+            acc[2] = fmaf(xw * y0, z1, acc[2]); acc[3] = fmaf(xw * y1, z1, acc[3]);
+        }
+    }
+    if (have) flush();
+}
+
 // ------------------------------------------------------------------ input gradient (H3)
 // GROUP = lanes that belong to one sample (L * LPI, a power of two <= 64): their partial
 // (dx,dy,dz) are summed with xor-shuffles and lane 0 of the group stores the result.
@@ -570,9 +641,18 @@ int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* d
         if (getenv("NGP_GRID_BWD_SIMPLE")) // one atomic per (sample, level, corner, feature): kept for A/B timing
             hipLaunchKernelGGL(grid_bwd_param_kernel<F>, dim3(ngp_blocks(n_items * F, 256)), dim3(256), 0, st, m, x,
                                dL_dy, lddy, n_items, dtable);
-        else
-            hipLaunchKernelGGL((grid_bwd_param_merge_kernel<F, CHUNK>), dim3(ngp_blocks(waves * 64, 256)), dim3(256), 0,
+        else if (F == 8 && !getenv("NGP_GRID_BWD_NOPAIR")) {
+            constexpr int LV2 = 64 / (2 * F) > 0 ? 64 / (2 * F) : 1;
+            const int64_t waves2 = ((n + CHUNK - 1) / CHUNK) * ((m.n_levels + LV2 - 1) / LV2);
+            hipLaunchKernelGGL((grid_bwd_param_merge2_kernel<F, CHUNK>), dim3(ngp_blocks(waves2 * 64, 256)), dim3(256), 0,
                                st, m, x, dL_dy, lddy, n, dtable);
+        } else {
+            // optional occupancy cap (unused dynamic LDS per block) so that a kernel on another
+            // stream can share the CUs with this atomic-bound one
+            static const int lds_pad = getenv("NGP_SCATTER_LDS") ? atoi(getenv("NGP_SCATTER_LDS")) : 0;
+            hipLaunchKernelGGL((grid_bwd_param_merge_kernel<F, CHUNK>), dim3(ngp_blocks(waves * 64, 256)), dim3(256),
+                               lds_pad, st, m, x, dL_dy, lddy, n, dtable);
+        }
     });
     return ngp_check_launch();
 }

@@ -71,6 +71,19 @@ class _LinearAct(Function):
 
 _RELU, _NONE = 1, 0
 
+import os as _os
+
+_OVERLAP = _os.environ.get("NGP_NO_OVERLAP", "0") != "1"
+_SIDE = {}
+
+
+def _side_stream(dev):
+    key = torch.device(dev).index
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=dev)
+    return st
+
 
 def _mlp2_backward(d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, ld_in, n_in, W1, ldw1, dW1, dW2,
                    db1, db2, dx, ld_dx, dx_cols, w1_col0, accumulate):
@@ -91,6 +104,15 @@ def _mlp2_backward(d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, l
     return dz1
 
 
+def _wait_params(model):
+    """The trainer may run clip + Adam on a side stream (overlapping the next step's ray marching);
+    anything that reads parameters first waits for that update."""
+    ev = getattr(model, "_params_ready", None)
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+        model._params_ready = None
+
+
 class _FieldFn(Function):
     """The whole NGP field (networks.py:198-240) as one autograd node: explicit kernel launches on
     preallocated buffers, no concat (both encoders write straight into rgb_net's input matrix),
@@ -106,6 +128,7 @@ class _FieldFn(Function):
     def forward(ctx, model, x, d, embed_a, xyz_table, W1, b1, W2, b2, rgb_table, rgb_p, nrm_p, sem_p):
         n = x.shape[0]
         dev = x.device
+        _wait_params(model)
         xe, re = model.xyz_encoder, model.rgb_encoder
         C = model.semantic_header.n_output_dims
         E = 0 if embed_a is None else embed_a.shape[1]
@@ -205,10 +228,25 @@ class _FieldFn(Function):
                 if buf is None:
                     g_rgbt = torch.zeros_like(rgb_table)
                     buf = g_rgbt
-                call("grid_bwd_param", re.desc, xn, dfeat_rgb, W_cols, n, buf)
-                cb = getattr(re, "on_grad_ready", None)
-                if cb is not None:
-                    cb()
+                # The colour-table scatter is bound by memory-side atomics, the density head's
+                # backward that follows by MFMA/LDS: run the scatter on a side stream so the two
+                # overlap (joined at the end of backward).
+                side = _side_stream(dev) if _OVERLAP else None
+                if side is not None:
+                    main = torch.cuda.current_stream()
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        call("grid_bwd_param", re.desc, xn, dfeat_rgb, W_cols, n, buf)
+                        cb = getattr(re, "on_grad_ready", None)
+                        if cb is not None:
+                            cb()
+                    dfeat_rgb.record_stream(side)
+                    xn.record_stream(side)
+                else:
+                    call("grid_bwd_param", re.desc, xn, dfeat_rgb, W_cols, n, buf)
+                    cb = getattr(re, "on_grad_ready", None)
+                    if cb is not None:
+                        cb()
             if E and need[3]:
                 g_emb = dfeat_rgb[:, 128:]
             if need[1]:
@@ -238,6 +276,8 @@ class _FieldFn(Function):
                 g_x = gx2 if g_x is None else g_x + gx2
         if g_x is not None:
             g_x = g_x / span
+        if _OVERLAP and dfeat_rgb is not None and need[9]:
+            torch.cuda.current_stream().wait_stream(_side_stream(dev))
         return (None, g_x, None, g_emb, g_xyz, g_W1, g_b1, g_W2, g_b2, g_rgbt, g_rgbp, g_nrm, g_sem)
 
 
@@ -320,6 +360,7 @@ class NGP(nn.Module):
     def density(self, x, return_feat=False, grad=True, grad_feat=True):
         """x (N,3) in [-scale, scale] -> sigmas (N) [, feat_rgb (N,128)]"""
         x = ((x - self.xyz_min) / (self.xyz_max - self.xyz_min)).contiguous()
+        _wait_params(self)
         if not (grad and torch.is_grad_enabled()):
             # inference (update_density_grid runs this on 1-2 M points): three launches, no graph
             with torch.no_grad():

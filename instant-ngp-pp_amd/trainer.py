@@ -124,6 +124,7 @@ class NGPTrainer:
         self.global_step = 0
         self.group = group
         self._flatten()
+        self._opt_stream = torch.cuda.Stream(device=self.flat_param.device) if self.flat_param.is_cuda else None
 
     # ------------------------------------------------------------------ flat parameter store
     def _flatten(self):
@@ -203,14 +204,25 @@ class NGPTrainer:
         self.global_step += 1
         # lr of the epoch this step belongs to (the scheduler ticks at epoch boundaries)
         lr = self.lr_at(min((self.global_step - 1) // self.steps_per_epoch, self.num_epochs))
-        self.scalars.zero_()
         if not self.sharded:
+            # clip + Adam stream 6.4 GB and touch no ray data: run them on a side stream so the next
+            # step's ray generation / AABB / marcher (latency bound, 128 waves) overlap; the field
+            # waits on `_params_ready` before it reads a parameter.
             n = self.flat_grad.numel()
-            call("sumsq", self.flat_grad, n, self.scalars[0:1])
-            call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2])
-            call("adam_step", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, n, float(lr), 0.9, 0.999,
-                 1e-8, 0.0, self.global_step, self.scalars[1:2], 1)
+            main = torch.cuda.current_stream()
+            side = self._opt_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.scalars.zero_()
+                call("sumsq", self.flat_grad, n, self.scalars[0:1])
+                call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2])
+                call("adam_step", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, n, float(lr), 0.9,
+                     0.999, 1e-8, 0.0, self.global_step, self.scalars[1:2], 1)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            self.model._params_ready = ev
             return
+        self.scalars.zero_()
         # sharded: bucket 0's reduce-scatter was issued from the colour encoder's backward
         nb = len(self.buckets.bounds) - 1
         for i in range(1 if self.hooked0 else 0, nb):
@@ -227,6 +239,13 @@ class NGPTrainer:
             self.buckets.all_gather_bucket(i, self.flat_param)
         self.flat_grad.zero_()              # the other ranks' slices hold partial sums: start clean
         self.buckets.wait()
+
+    def wait(self):
+        """make the current stream wait for a pending side-stream optimizer step (call before reading
+        parameters / gradients outside the model's own forward)"""
+        ev = getattr(self.model, "_params_ready", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     # ------------------------------------------------------------------ multi-GPU helpers
     def broadcast_state(self, src=0):

@@ -594,6 +594,7 @@ def test_trainer_steps_reduce_loss(ngp):
         gt, _ = scene.ground_truth(o, d, n_quad=128)
         loss, res = tr.step(o, d, gt)
         losses.append(float(loss))
+    tr.wait()
     assert np.isfinite(losses).all()
     assert np.mean(losses[-5:]) < 0.5 * np.mean(losses[:5])
     assert torch.isfinite(tr.flat_param).all()

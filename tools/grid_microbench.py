@@ -23,9 +23,6 @@ coords = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=
 model.register_buffer("grid_coords", coords.reshape(-1, 3).contiguous())
 scene = LegoProxy(device=dev)
 tr = NGPTrainer(model)
-model.density_grid.copy_(scene.occupancy_from_analytic(model))
-ngp_amd.vren.packbits(model.density_grid.view(-1), 0.5, model.density_bitfield)
-tr.global_step, tr.warmup_steps = 1024, 0
 gen = torch.Generator(device=dev).manual_seed(1)
 
 captured = {}
@@ -64,24 +61,28 @@ def timeit(fn, reps=20):
 
 
 for idx, args in enumerate(captured["grid_bwd_param"]):
-    desc, x, dy, n, buf = args
+    desc, x, dy, lddy, n, buf = args
     nz_rows = (dy.abs().sum(1) > 0).float().mean().item()
     nz_el = (dy != 0).float().mean().item()
     tbl = torch.zeros(desc.offsets[desc.n_levels] * desc.n_features, device=dev)
-    for variant in os.environ.get("MB_VARIANTS", "merge,simple").split(","):
+    for variant in os.environ.get("MB_VARIANTS", "pair,merge,simple").split(","):
         os.environ.pop("NGP_GRID_BWD_SIMPLE", None)
+        os.environ.pop("NGP_GRID_BWD_NOPAIR", None)
         if variant == "simple":
             os.environ["NGP_GRID_BWD_SIMPLE"] = "1"
-        ms = timeit(lambda: orig_call("grid_bwd_param", desc, x, dy, n, tbl))
+        if variant == "merge":
+            os.environ["NGP_GRID_BWD_NOPAIR"] = "1"
+        ms = timeit(lambda: orig_call("grid_bwd_param", desc, x, dy, lddy, n, tbl))
         print(f"bwd_param[{idx}] table_rows={desc.offsets[desc.n_levels]} n={n} nonzero_rows={nz_rows:.3f} nonzero_el={nz_el:.3f} "
               f"{variant}: {ms:.3f} ms  alg {n*4608/ms/1e6:.0f} GB/s  (nonzero-only {n*nz_rows*4608/ms/1e6:.0f} GB/s)")
     os.environ.pop("NGP_GRID_BWD_SIMPLE", None)
+    os.environ.pop("NGP_GRID_BWD_NOPAIR", None)
     # all-nonzero gradient for the same positions: the kernel's ceiling without sparsity
     dyr = torch.randn_like(dy)
-    ms = timeit(lambda: orig_call("grid_bwd_param", desc, x, dyr, n, tbl))
+    ms = timeit(lambda: orig_call("grid_bwd_param", desc, x, dyr, lddy, n, tbl))
     print(f"   dense random dy: {ms:.3f} ms  alg {n*4608/ms/1e6:.0f} GB/s")
 for name in ("grid_fwd", "grid_bwd_input"):
     for idx, args in enumerate(captured.get(name, [])):
-        n = [a for a in args if isinstance(a, int)][0]
+        n = [a for a in args if isinstance(a, int)][0 if name == "grid_fwd" else 1]
         ms = timeit(lambda: orig_call(name, *args))
         print(f"{name}[{idx}] n={n}: {ms:.3f} ms  alg {n*4608/ms/1e6:.0f} GB/s")
