@@ -15,7 +15,7 @@ Every compute call goes through libngp_hip.so (include/ngp_hip.h); there is no C
 from . import _lib  # noqa: F401  (parses the header; the .so is loaded on first use)
 
 __all__ = ["vren", "tinycudann", "torch_scatter", "custom_functions", "rendering", "networks", "losses",
-           "metrics", "trainer", "install_as_reference_modules"]
+           "metrics", "trainer", "synthetic", "ckpt", "install_as_reference_modules"]
 
 
 def __getattr__(name):

@@ -8,11 +8,12 @@ keys (`xyz_encoder.params`, `xyz_net.0.weight`, `rgb_net.params`, ...), so refer
 checkpoints map one to one.
 
 Differences, all deliberate:
-  * d(sigma)/dx is computed analytically in the forward pass (sigmoid-gated back-substitution
-    through the 2-layer density MLP + the grid input-gradient kernel) instead of
+  * by default d(sigma)/dx is computed analytically in the forward pass (sigmoid-gated
+    back-substitution through the 2-layer density MLP + the grid input-gradient kernel) instead of
     torch.autograd.grad(create_graph=True) (networks.py:186-196).  The values are identical; the
-    result is detached, i.e. normals_raw carries no gradient (the double backward H4 is only
-    needed with --normal_ref and is exposed through tinycudann.Encoding, not wired in here yet).
+    result is detached, i.e. normals_raw carries no gradient — which is what every recipe without
+    --normal_ref needs.  Setting `model.differentiable_normals = True` switches forward() to the
+    reference's own formulation, with the grid double backward (H4) on ngp_grid_bwd_bwd_input.
 """
 import numpy as np
 import torch
@@ -413,9 +414,35 @@ class NGP(nn.Module):
                 rgbs = self.log_radiance_to_rgb(rgbs, **kwargs)
         return rgbs
 
+    def _forward_differentiable_normals(self, x, d, kwargs):
+        """The reference's own formulation (networks.py:186-240): d(sigma)/dx by
+        torch.autograd.grad(create_graph=True), so that normals_raw carries gradients back into the
+        density table and MLP (H4, needed by --normal_ref).  The grid's double backward runs on
+        ngp_grid_bwd_bwd_input; the 17 k-parameter density MLP uses torch ops here."""
+        _wait_params(self)
+        x = x.detach().clone().requires_grad_(True)
+        xn = (x - self.xyz_min) / (self.xyz_max - self.xyz_min)
+        with torch.enable_grad():
+            h = self.xyz_net(self.xyz_encoder(xn))
+            sigmas = self.sigma_act(h[:, 0])
+            grads = torch.autograd.grad(sigmas, x, torch.ones_like(sigmas), create_graph=True)[0]
+        feat_rgb = self.rgb_encoder(xn.detach())
+        dn = F.normalize(d, p=2, dim=-1, eps=1e-6)
+        cols = [self.dir_encoder((dn + 1) / 2), feat_rgb]
+        if self.embed_a:
+            embed_a = kwargs['embedding_a']
+            if embed_a.size(0) < feat_rgb.size(0):
+                embed_a = torch.repeat_interleave(embed_a, int(feat_rgb.size(0) / embed_a.size(0)), 0)
+            cols.append(embed_a)
+        rgbs = self.rgb_net(torch.cat(cols, 1))
+        return sigmas, rgbs, grads, self.norm_pred_header(feat_rgb), self.semantic_header(feat_rgb)
+
     def forward(self, x, d, **kwargs):
         """x, d (N,3) -> sigmas (N), rgbs (N,3), normals_raw (N,3), normals_pred (N,3), semantic (N,C)"""
-        sigmas, rgbs, grads, np_raw, sem_logits = self._field(x, d, kwargs)
+        if getattr(self, 'differentiable_normals', False) and torch.is_grad_enabled():
+            sigmas, rgbs, grads, np_raw, sem_logits = self._forward_differentiable_normals(x, d, kwargs)
+        else:
+            sigmas, rgbs, grads, np_raw, sem_logits = self._field(x, d, kwargs)
         normals_raw = -F.normalize(grads, p=2, dim=-1, eps=1e-6)
         normals_pred = -F.normalize(np_raw, p=2, dim=-1, eps=1e-6)
         semantic = self.semantic_act(sem_logits)

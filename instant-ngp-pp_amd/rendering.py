@@ -37,6 +37,20 @@ def render(model, rays_o, rays_d, **kwargs):
     return results
 
 
+def render_chunks(model, rays_o, rays_d, chunk_size, **kwargs):
+    """render() in chunks of `chunk_size` rays (render.py:33-48): per-ray results concatenated,
+    `total_samples` kept as a list"""
+    results = {}
+    for i in range(0, rays_o.shape[0], chunk_size):
+        ret = render(model, rays_o[i:i + chunk_size], rays_d[i:i + chunk_size], **dict(kwargs))
+        for k, v in ret.items():
+            results.setdefault(k, []).append(v)
+    for k in results:
+        if k != 'total_samples':
+            results[k] = torch.cat(results[k], 0)
+    return results
+
+
 def volume_render(model, rays_o, rays_d, hits_t, opacity, depth, rgb, normal_pred, normal_raw, sem, **kwargs):
     """Progressive test-time marching (rendering.py:46-133): the per-ray accumulators are updated
     in place; returns the total number of samples evaluated."""

@@ -602,3 +602,44 @@ def test_trainer_steps_reduce_loss(ngp):
     assert tr.global_step == 40
     # parameters are views of the flat buffer (state-dict keys stay the reference's)
     assert model.rgb_encoder.params.data_ptr() == tr.flat_param.data_ptr()
+
+
+def test_differentiable_normals_h4(ngp):
+    """--normal_ref path: a loss on normals_raw reaches the density table through the grid's double
+    backward; checked against a central difference along a random direction in parameter space."""
+    model = _make_model(ngp)
+    g = rng(230)
+    n = 300
+    x = T(((g.random((n, 3)) - 0.5) * 0.9).astype(np.float32))
+    d = T(g.normal(size=(n, 3)).astype(np.float32))
+    w = T(g.normal(size=(n, 3)).astype(np.float32))
+    # same values as the fused node
+    with torch.no_grad():
+        _, _, n_fused, _, _ = model(x, d)
+    model.differentiable_normals = True
+    sig, rgb, n_raw, n_pred, sem = model(x, d)
+    close(N(n_raw), N(n_fused), 1e-3, 1e-4)
+
+    def loss_fn():
+        _, _, nr, _, _ = model(x, d)
+        return (nr * w).sum()
+
+    loss = loss_fn()
+    params = [model.xyz_encoder.params, model.xyz_net[0].weight, model.xyz_net[2].weight]
+    grads = torch.autograd.grad(loss, params)
+    assert all(torch.isfinite(gr).all() and gr.abs().sum() > 0 for gr in grads)
+    torch.manual_seed(1)
+    dirs = [torch.randn_like(p) for p in params]
+    analytic = sum(float((gr.double() * dd.double()).sum()) for gr, dd in zip(grads, dirs))
+    eps = 2e-4
+    with torch.no_grad():
+        for p, dd in zip(params, dirs):
+            p.add_(eps * dd)
+        lp = float(loss_fn())
+        for p, dd in zip(params, dirs):
+            p.sub_(2 * eps * dd)
+        lm = float(loss_fn())
+        for p, dd in zip(params, dirs):
+            p.add_(eps * dd)
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - analytic) < 0.05 * max(abs(fd), abs(analytic), 1.0), (fd, analytic)
