@@ -147,7 +147,9 @@ int ngp_composite_test_fw(const float* sigmas, const float* rgbs, const float* n
  * One 32-lane half-wave per rays_a row, segmented transmittance scan, early stop
  * at T <= T_threshold.  Every per-sample output row of the ray is written (zeros
  * past the stop), so callers need not pre-zero per-sample outputs; per-ray
- * outputs are written for every rays_a row.
+ * outputs are written for every rays_a row.  In ngp_composite_train_bw the outputs
+ * dL_dnormals_pred / dL_dsems may be NULL (together with their upstream gradients)
+ * when the loss does not use the composited normal / semantic maps.
  * ---------------------------------------------------------------------- */
 int ngp_composite_alpha_fw(const float* sigmas, const float* deltas, const int64_t* rays_a,
                            float T_threshold, int n_rays, float* alphas, float* ws, void* stream);
@@ -197,6 +199,26 @@ int ngp_distortion_loss_bw(const float* dL_dloss, const float* ws_inclusive_scan
                            const float* wts_inclusive_scan, const float* ws, const float* deltas,
                            const float* ts, const int64_t* rays_a, int n_rays,
                            float* dL_dws, void* stream);
+
+/* ------------------------------------------------------------------------
+ * L1  loss glue, fused (each replaces a chain of torch elementwise ops in the reference)
+ * ngp_nerf_loss      : NeRFLoss rgb + opacity terms (losses.py:96-100): sums[0] += sum (rgb-gt)^2,
+ *                      sums[1] += sum -o log o (o = opacity+1e-10), and their gradients for the
+ *                      mean-reduced loss: d_rgb = 2(rgb-gt)/(3n), d_opacity = lambda(-log o - 1)/n.
+ * ngp_refloss_inputs : normals_diff = (n_raw-n_pred)^2, normals_ori = max(<n_raw, normalize(dir)>,0)^2
+ *                      (rendering.py:243-245).
+ * ngp_neg_normalize  : y = -F.normalize(x*scale3, eps=1e-6) on rows of 3 (networks.py:210,215), and
+ *                      its backward.
+ * ---------------------------------------------------------------------- */
+int ngp_nerf_loss(const float* rgb, const float* target_rgb, const float* opacity, int n_rays,
+                  float lambda_opacity, float* sums /* (2), caller zeroes */, float* d_rgb,
+                  float* d_opacity, void* stream);
+int ngp_refloss_inputs(const float* normals_raw, const float* normals_pred, const float* dirs, int64_t n,
+                       float* normals_diff, float* normals_ori, void* stream);
+int ngp_neg_normalize(const float* x, int64_t ldx, const float* scale3 /* device (3) or NULL */, int64_t n,
+                      float* y, void* stream);
+int ngp_neg_normalize_bwd(const float* x, int64_t ldx, const float* dL_dy, int64_t n, float* dL_dx,
+                          void* stream);
 
 /* ------------------------------------------------------------------------
  * R4  torch_scatter.segment_csr(src, indptr) with sum reduction

@@ -159,10 +159,11 @@ __global__ void composite_train_bw_kernel(const float* __restrict__ dL_dopacity,
     const float O = opacity[r], D = depth[r];
     const float gR = dL_drgb[3 * r], gG = dL_drgb[3 * r + 1], gB = dL_drgb[3 * r + 2];
     const float gO = dL_dopacity[r], gD = dL_ddepth[r];
-    const float gNx = dL_dnormal[3 * r], gNy = dL_dnormal[3 * r + 1], gNz = dL_dnormal[3 * r + 2];
+    float gNx = 0.0f, gNy = 0.0f, gNz = 0.0f;
+    if (dL_dnormals) { gNx = dL_dnormal[3 * r]; gNy = dL_dnormal[3 * r + 1]; gNz = dL_dnormal[3 * r + 2]; }
     float gS[CMAX > 0 ? CMAX : 1];
 #pragma unroll
-    for (int cc = 0; cc < CMAX; cc++) gS[cc] = cc < classes ? dL_dsem[r * classes + cc] : 0.0f;
+    for (int cc = 0; cc < CMAX; cc++) gS[cc] = (dL_dsems && cc < classes) ? dL_dsem[r * classes + cc] : 0.0f;
 
     // total of dL_dws*ws over the whole segment (volumerendering.cu:206-210)
     float tot = 0.0f;
@@ -189,10 +190,14 @@ __global__ void composite_train_bw_kernel(const float* __restrict__ dL_dopacity,
         if (c.valid) {
             const float wa = c.active ? w : 0.0f;
             dL_drgbs[3 * s] = gR * wa; dL_drgbs[3 * s + 1] = gG * wa; dL_drgbs[3 * s + 2] = gB * wa;
-            dL_dnormals[3 * s] = gNx * wa; dL_dnormals[3 * s + 1] = gNy * wa; dL_dnormals[3 * s + 2] = gNz * wa;
+            if (dL_dnormals) {
+                dL_dnormals[3 * s] = gNx * wa; dL_dnormals[3 * s + 1] = gNy * wa; dL_dnormals[3 * s + 2] = gNz * wa;
+            }
+            if (dL_dsems) {
 #pragma unroll
-            for (int cc = 0; cc < CMAX; cc++)
-                if (cc < classes) dL_dsems[s * classes + cc] = gS[cc] * wa;
+                for (int cc = 0; cc < CMAX; cc++)
+                    if (cc < classes) dL_dsems[s * classes + cc] = gS[cc] * wa;
+            }
             const float T = c.T_after;
             const float v = dl * (gR * (cr * T - (R - ri)) +
                                   gG * (cg * T - (G - gi)) +
@@ -213,8 +218,8 @@ __global__ void composite_train_bw_kernel(const float* __restrict__ dL_dopacity,
             const int64_t s = sg.start + k;
             dL_dsigmas[s] = 0.0f;
             dL_drgbs[3 * s] = 0.0f; dL_drgbs[3 * s + 1] = 0.0f; dL_drgbs[3 * s + 2] = 0.0f;
-            dL_dnormals[3 * s] = 0.0f; dL_dnormals[3 * s + 1] = 0.0f; dL_dnormals[3 * s + 2] = 0.0f;
-            for (int cc = 0; cc < classes; cc++) dL_dsems[s * classes + cc] = 0.0f;
+            if (dL_dnormals) { dL_dnormals[3 * s] = 0.0f; dL_dnormals[3 * s + 1] = 0.0f; dL_dnormals[3 * s + 2] = 0.0f; }
+            if (dL_dsems) for (int cc = 0; cc < classes; cc++) dL_dsems[s * classes + cc] = 0.0f;
         }
     }
 }
@@ -435,6 +440,88 @@ __global__ void segment_csr_kernel(const float* __restrict__ src, const int64_t*
     }
 }
 
+// ------------------------------------------------------------------ fused loss / glue kernels
+// NeRFLoss rgb + opacity terms (losses.py:96-100) with their gradients in one pass:
+//   sums[0] += sum (rgb-gt)^2          d_rgb     = g_rgb * 2 (rgb-gt)            g_rgb = 1/(3 n)
+//   sums[1] += sum -o log o, o=op+1e-10 d_opacity = g_op * (-log o - 1)          g_op = lambda/n
+__global__ void __launch_bounds__(256) nerf_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ gt,
+                                                        const float* __restrict__ opacity, int n_rays, float g_rgb,
+                                                        float g_op, float* __restrict__ sums,
+                                                        float* __restrict__ d_rgb, float* __restrict__ d_opacity)
+{
+    __shared__ float part[2][4];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (r < n_rays) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float e = rgb[3 * r + c] - gt[3 * r + c];
+            s0 += e * e;
+            d_rgb[3 * r + c] = g_rgb * 2.0f * e;
+        }
+        const float o = opacity[r] + 1e-10f;
+        const float lg = logf(o);
+        s1 = -o * lg;
+        d_opacity[r] = g_op * (-lg - 1.0f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s0; part[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sums, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        atomicAdd(sums + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+    }
+}
+
+// Inputs of RefLoss (rendering.py:243-245): normals_diff = (n_raw - n_pred)^2,
+// normals_ori = max(<n_raw, normalize(dir)>, 0)^2
+__global__ void refloss_inputs_kernel(const float* __restrict__ n_raw, const float* __restrict__ n_pred,
+                                      const float* __restrict__ dirs, int64_t n, float* __restrict__ ndiff,
+                                      float* __restrict__ nori)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float rx = n_raw[3 * i], ry = n_raw[3 * i + 1], rz = n_raw[3 * i + 2];
+    const float ex = rx - n_pred[3 * i], ey = ry - n_pred[3 * i + 1], ez = rz - n_pred[3 * i + 2];
+    ndiff[3 * i] = ex * ex; ndiff[3 * i + 1] = ey * ey; ndiff[3 * i + 2] = ez * ez;
+    const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
+    const float inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
+    const float dot = fmaxf((rx * dx + ry * dy + rz * dz) * inv, 0.0f);
+    nori[i] = dot * dot;
+}
+
+// y = -normalize(x * scale, eps=1e-6)  (F.normalize semantics: x / max(|x|, eps)); rows of 3
+__global__ void neg_normalize_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ scale3,
+                                     int64_t n, float* __restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = x[i * ldx], b = x[i * ldx + 1], c = x[i * ldx + 2];
+    if (scale3) { a *= scale3[0]; b *= scale3[1]; c *= scale3[2]; }
+    const float inv = -1.0f / fmaxf(sqrtf(a * a + b * b + c * c), 1e-6f);
+    y[3 * i] = a * inv; y[3 * i + 1] = b * inv; y[3 * i + 2] = c * inv;
+}
+
+// backward of y = -x/max(|x|,eps):  dx = -(g - u <u,g>)/|x| with u = x/|x|   (|x| > eps)
+__global__ void neg_normalize_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ g,
+                                         int64_t n, float* __restrict__ dx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = x[i * ldx], b = x[i * ldx + 1], c = x[i * ldx + 2];
+    const float ga = g[3 * i], gb = g[3 * i + 1], gc = g[3 * i + 2];
+    const float nrm = sqrtf(a * a + b * b + c * c);
+    if (nrm > 1e-6f) {
+        const float inv = 1.0f / nrm;
+        const float ua = a * inv, ub = b * inv, uc = c * inv;
+        const float dot = ua * ga + ub * gb + uc * gc;
+        dx[3 * i] = -(ga - ua * dot) * inv; dx[3 * i + 1] = -(gb - ub * dot) * inv; dx[3 * i + 2] = -(gc - uc * dot) * inv;
+    } else {
+        dx[3 * i] = -ga * 1e6f; dx[3 * i + 1] = -gb * 1e6f; dx[3 * i + 2] = -gc * 1e6f;
+    }
+}
+
 inline dim3 seg_grid(int n_rays) { return dim3(ngp_blocks((int64_t)n_rays * 32, 256)); }
 
 } // namespace
@@ -489,7 +576,8 @@ int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
     (void)normals_pred; (void)normal_pred;
     if (n_rays < 0 || classes < 0) return NGP_EINVAL;
     if (n_rays == 0) return NGP_OK;
-    if (!rays_a || !dL_dsigmas || !dL_drgbs || !dL_dnormals_pred || (classes && !dL_dsems)) return NGP_EINVAL;
+    if (!rays_a || !dL_dsigmas || !dL_drgbs) return NGP_EINVAL;
+    if ((dL_dnormals_pred && !dL_dnormal_pred) || (dL_dsems && classes && !dL_dsem)) return NGP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_BW(CM, CL)                                                                                          \
     hipLaunchKernelGGL(composite_train_bw_kernel<CM>, seg_grid(n_rays), dim3(256), 0, st, dL_dopacity, dL_ddepth,  \
@@ -502,8 +590,9 @@ int ngp_composite_train_bw(const float* dL_dopacity, const float* dL_ddepth, con
     else {
         // ws saved by the forward is exactly the effective weight (zero behind the stop)
         LAUNCH_BW(0, 0);
-        hipLaunchKernelGGL(composite_sem_bw_kernel, seg_grid(n_rays), dim3(256), 0, st, dL_dsem, ws, rays_a, classes,
-                           n_rays, dL_dsems);
+        if (dL_dsems)
+            hipLaunchKernelGGL(composite_sem_bw_kernel, seg_grid(n_rays), dim3(256), 0, st, dL_dsem, ws, rays_a, classes,
+                               n_rays, dL_dsems);
     }
 #undef LAUNCH_BW
     return ngp_check_launch();
@@ -575,6 +664,47 @@ int ngp_distortion_loss_bw(const float* dL_dloss, const float* ws_inclusive_scan
     if (!rays_a || !dL_dloss || !dL_dws) return NGP_EINVAL;
     hipLaunchKernelGGL(distortion_bw_kernel, seg_grid(n_rays), dim3(256), 0, (hipStream_t)stream, dL_dloss,
                        ws_inclusive_scan, wts_inclusive_scan, ws, deltas, ts, rays_a, n_rays, dL_dws);
+    return ngp_check_launch();
+}
+
+int ngp_nerf_loss(const float* rgb, const float* target_rgb, const float* opacity, int n_rays, float lambda_opacity,
+                  float* sums, float* d_rgb, float* d_opacity, void* stream)
+{
+    if (n_rays < 1 || !rgb || !target_rgb || !opacity || !sums || !d_rgb || !d_opacity) return NGP_EINVAL;
+    hipLaunchKernelGGL(nerf_loss_kernel, dim3(ngp_blocks(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, rgb,
+                       target_rgb, opacity, n_rays, 1.0f / (3.0f * n_rays), lambda_opacity / n_rays, sums, d_rgb,
+                       d_opacity);
+    return ngp_check_launch();
+}
+
+int ngp_refloss_inputs(const float* normals_raw, const float* normals_pred, const float* dirs, int64_t n,
+                       float* normals_diff, float* normals_ori, void* stream)
+{
+    if (n < 0) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!normals_raw || !normals_pred || !dirs || !normals_diff || !normals_ori) return NGP_EINVAL;
+    hipLaunchKernelGGL(refloss_inputs_kernel, dim3(ngp_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, normals_raw,
+                       normals_pred, dirs, n, normals_diff, normals_ori);
+    return ngp_check_launch();
+}
+
+int ngp_neg_normalize(const float* x, int64_t ldx, const float* scale3, int64_t n, float* y, void* stream)
+{
+    if (n < 0 || ldx < 3) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!x || !y) return NGP_EINVAL;
+    hipLaunchKernelGGL(neg_normalize_kernel, dim3(ngp_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       scale3, n, y);
+    return ngp_check_launch();
+}
+
+int ngp_neg_normalize_bwd(const float* x, int64_t ldx, const float* dL_dy, int64_t n, float* dL_dx, void* stream)
+{
+    if (n < 0 || ldx < 3) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!x || !dL_dy || !dL_dx) return NGP_EINVAL;
+    hipLaunchKernelGGL(neg_normalize_bwd_kernel, dim3(ngp_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       dL_dy, n, dL_dx);
     return ngp_check_launch();
 }
 

@@ -644,8 +644,11 @@ int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* d
         else if (F == 8 && !getenv("NGP_GRID_BWD_NOPAIR")) {
             constexpr int LV2 = 64 / (2 * F) > 0 ? 64 / (2 * F) : 1;
             const int64_t waves2 = ((n + CHUNK - 1) / CHUNK) * ((m.n_levels + LV2 - 1) / LV2);
-            hipLaunchKernelGGL((grid_bwd_param_merge2_kernel<F, CHUNK>), dim3(ngp_blocks(waves2 * 64, 256)), dim3(256), 0,
-                               st, m, x, dL_dy, lddy, n, dtable);
+            // optional occupancy cap (unused dynamic LDS per block) so that a kernel on another
+            // stream can share the CUs with this atomic-bound one
+            const char* cap = getenv("NGP_SCATTER_LDS");
+            hipLaunchKernelGGL((grid_bwd_param_merge2_kernel<F, CHUNK>), dim3(ngp_blocks(waves2 * 64, 256)), dim3(256),
+                               cap ? atoi(cap) : 0, st, m, x, dL_dy, lddy, n, dtable);
         } else {
             // optional occupancy cap (unused dynamic LDS per block) so that a kernel on another
             // stream can share the CUs with this atomic-bound one

@@ -79,21 +79,30 @@ class VolumeRenderer(torch.autograd.Function):
         ctx.save_for_backward(sigmas, rgbs, normals_pred, deltas, ts, rays_a, opacity, depth, rgb, normal_pred, ws)
         ctx.T_threshold = T_threshold
         ctx.classes = classes
+        ctx.set_materialize_grads(False)  # outputs the loss never touched arrive as None, not zeros
         return total.sum(), opacity, depth, rgb, normal_pred, sem, ws
 
     @staticmethod
     def backward(ctx, dL_dtotal_samples, dL_dopacity, dL_ddepth, dL_drgb, dL_dnormal_pred, dL_dsem, dL_dws):
         sigmas, rgbs, normals_pred, deltas, ts, rays_a, opacity, depth, rgb, normal_pred, ws = ctx.saved_tensors
         N, classes = sigmas.shape[0], ctx.classes
+        nr = rays_a.shape[0]
         dev = sigmas.device
+
+        def z(t, *shape):
+            return torch.zeros(*shape, dtype=_f32, device=dev) if t is None else t.contiguous()
+
+        # The reference back-propagates all-zero gradients through the normal / semantic heads when
+        # the loss ignores those maps; here they are simply not produced (None) and the field's
+        # backward skips the heads.
         d_sig = torch.empty(N, dtype=_f32, device=dev)
         d_rgbs = torch.empty(N, 3, dtype=_f32, device=dev)
-        d_nrm = torch.empty(N, 3, dtype=_f32, device=dev)
-        d_sems = torch.empty(N, classes, dtype=_f32, device=dev)
-        call("composite_train_bw", dL_dopacity.contiguous(), dL_ddepth.contiguous(), dL_drgb.contiguous(),
-             dL_dnormal_pred.contiguous(), dL_dsem.contiguous(), dL_dws.contiguous(), sigmas, rgbs, normals_pred, ws,
-             deltas, ts, rays_a, opacity, depth, rgb, normal_pred, float(ctx.T_threshold), int(classes),
-             rays_a.shape[0], d_sig, d_rgbs, d_nrm, d_sems)
+        d_nrm = torch.empty(N, 3, dtype=_f32, device=dev) if dL_dnormal_pred is not None else None
+        d_sems = torch.empty(N, classes, dtype=_f32, device=dev) if dL_dsem is not None else None
+        call("composite_train_bw", z(dL_dopacity, nr), z(dL_ddepth, nr), z(dL_drgb, nr, 3),
+             None if d_nrm is None else dL_dnormal_pred.contiguous(), None if d_sems is None else dL_dsem.contiguous(),
+             z(dL_dws, N), sigmas, rgbs, normals_pred, ws, deltas, ts, rays_a, opacity, depth, rgb, normal_pred,
+             float(ctx.T_threshold), int(classes), nr, d_sig, d_rgbs, d_nrm, d_sems)
         return d_sig, d_rgbs, d_nrm, d_sems, None, None, None, None, None
 
 

@@ -43,6 +43,42 @@ class DistortionLoss(torch.autograd.Function):
         return dL_dws, None, None, None
 
 
+class FusedNeRFLoss(torch.autograd.Function):
+    """sum(term.mean()) of NeRFLoss's default terms — rgb MSE, opacity entropy, distortion
+    (losses.py:96-105, train.py:307) — with the gradients produced in the same three launches.
+    Returns (loss, rgb_mse_mean, opacity_mean, distortion_mean); only `loss` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, rgb, opacity, ws, deltas, ts, rays_a, target_rgb, lambda_opa, lambda_distortion):
+        from ._lib import call
+        nr = rgb.shape[0]
+        dev = rgb.device
+        rgb, opacity, ws = rgb.contiguous(), opacity.contiguous(), ws.contiguous()
+        sums = torch.zeros(2, dtype=torch.float32, device=dev)
+        d_rgb = torch.empty(nr, 3, dtype=torch.float32, device=dev)
+        d_op = torch.empty(nr, dtype=torch.float32, device=dev)
+        call("nerf_loss", rgb, target_rgb.contiguous(), opacity, nr, float(lambda_opa), sums, d_rgb, d_op)
+        t_rgb = sums[0] / (3 * nr)
+        t_op = sums[1] * (lambda_opa / nr)
+        loss = t_rgb + t_op
+        d_ws = None
+        t_dist = torch.zeros((), dtype=torch.float32, device=dev)
+        if lambda_distortion > 0:
+            dist, wi, wti = vren.distortion_loss_fw(ws, deltas, ts, rays_a)
+            t_dist = dist.mean() * lambda_distortion
+            loss = loss + t_dist
+            g = torch.full((nr,), lambda_distortion / nr, dtype=torch.float32, device=dev)
+            d_ws = vren.distortion_loss_bw(g, wi, wti, ws, deltas, ts, rays_a)
+        ctx.save_for_backward(d_rgb, d_op, d_ws)
+        ctx.mark_non_differentiable(t_rgb, t_op, t_dist)
+        return loss, t_rgb, t_op, t_dist
+
+    @staticmethod
+    def backward(ctx, g, *_unused):
+        d_rgb, d_op, d_ws = ctx.saved_tensors
+        return d_rgb * g, d_op * g, (None if d_ws is None else d_ws * g), None, None, None, None, None, None
+
+
 class ExponentialAnnealingWeight():
     def __init__(self, max, min, k):
         self.max, self.min, self.k = max, min, k

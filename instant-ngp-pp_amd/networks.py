@@ -105,6 +105,26 @@ def _mlp2_backward(d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, l
     return dz1
 
 
+class _NegNormalize(Function):
+    """y = -F.normalize(x * scale3, p=2, dim=-1, eps=1e-6) on (N,3) rows, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, x, scale3):
+        x = x.contiguous()
+        y = torch.empty(x.shape[0], 3, dtype=_f32, device=x.device)
+        call("neg_normalize", x, 3, scale3, x.shape[0], y)
+        if scale3 is None:
+            ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        call("neg_normalize_bwd", x, 3, g.contiguous(), x.shape[0], dx)
+        return dx, None
+
+
 def _wait_params(model):
     """The trainer may run clip + Adam on a side stream (overlapping the next step's ray marching);
     anything that reads parameters first waits for that update."""
@@ -121,7 +141,8 @@ class _FieldFn(Function):
     gradient (normal / semantic heads are skipped when the loss does not use them).
 
     inputs : x (N,3) world, d (N,3), embed_a (N,E) or None, then the 9 parameter tensors
-    outputs: sigma (N), rgb (N,3) [after rgb_net's output activation], dsigma_dx (N,3) [no grad],
+    outputs: sigma (N), rgb (N,3) [after rgb_net's output activation], dsigma/dxn (N,3) w.r.t. the
+             normalised position (no grad; divide by xyz_max-xyz_min for world units),
              normal head (N,3) raw, semantic logits (N,C)
     """
 
@@ -150,9 +171,8 @@ class _FieldFn(Function):
         call("mlp_hidden_bwd", None, 0, sig, 1, _SOFTPLUS, W2, 128, a1, 128, _SOFTPLUS, n, 128, 1, None, 0, dz1, 128)
         dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
         call("linear_bwd_input", dz1, 128, W1, 128, n, 128, 128, dfeat, 128, 0)
-        grads = torch.empty(n, 3, dtype=_f32, device=dev)
+        grads = torch.empty(n, 3, dtype=_f32, device=dev)   # d sigma / d xn (normalised coordinates)
         call("grid_bwd_input", xe.desc, xyz_table, xn, dfeat, 128, n, grads)
-        grads = grads / span
         del dz1, dfeat
 
         # colour branch: [SH(16) | rgb grid features (128) | appearance code (E) | ones-padding]
@@ -403,9 +423,15 @@ class NGP(nn.Module):
             x.shape[0], self.rgb_net.n_input_dims - 144, device=x.device)} if self.embed_a else {})
         span = self.xyz_max - self.xyz_min
         feat_rgb = self.rgb_encoder(((x - self.xyz_min) / span).contiguous())
-        return sigmas, feat_rgb, grads
+        return sigmas, feat_rgb, grads / span
 
     # ------------------------------------------------------------------ full field
+    def _inv_span(self):
+        inv = getattr(self, '_inv_span_t', None)
+        if inv is None or inv.device != self.xyz_min.device:
+            inv = self._inv_span_t = (1.0 / (self.xyz_max - self.xyz_min)).reshape(3).contiguous()
+        return inv
+
     def _tone(self, rgbs, kwargs):
         if self.rgb_act == 'None':  # rgb_net outputs log-radiance
             if kwargs.get('output_radiance', False):
@@ -441,10 +467,11 @@ class NGP(nn.Module):
         """x, d (N,3) -> sigmas (N), rgbs (N,3), normals_raw (N,3), normals_pred (N,3), semantic (N,C)"""
         if getattr(self, 'differentiable_normals', False) and torch.is_grad_enabled():
             sigmas, rgbs, grads, np_raw, sem_logits = self._forward_differentiable_normals(x, d, kwargs)
+            normals_raw = -F.normalize(grads, p=2, dim=-1, eps=1e-6)
         else:
             sigmas, rgbs, grads, np_raw, sem_logits = self._field(x, d, kwargs)
-        normals_raw = -F.normalize(grads, p=2, dim=-1, eps=1e-6)
-        normals_pred = -F.normalize(np_raw, p=2, dim=-1, eps=1e-6)
+            normals_raw = _NegNormalize.apply(grads, self._inv_span())
+        normals_pred = _NegNormalize.apply(np_raw, None)
         semantic = self.semantic_act(sem_logits)
         return sigmas, self._tone(rgbs, kwargs), normals_raw, normals_pred, semantic
 
@@ -452,8 +479,8 @@ class NGP(nn.Module):
         """same as forward but returns (sigmas, rgbs, normals_pred, normals_raw, semantic) — the
         reference's test path swaps the two normals (networks.py:282) and detaches the heads."""
         sigmas, rgbs, grads, np_raw, sem_logits = self._field(x, d, kwargs)
-        normals_raw = -F.normalize(grads, p=2, dim=-1, eps=1e-6)
-        normals_pred = -F.normalize(np_raw.detach(), p=2, dim=-1, eps=1e-6)
+        normals_raw = _NegNormalize.apply(grads, self._inv_span())
+        normals_pred = _NegNormalize.apply(np_raw.detach(), None)
         semantic = self.semantic_act(sem_logits.detach())
         return sigmas, self._tone(rgbs, kwargs), normals_pred, normals_raw, semantic
 

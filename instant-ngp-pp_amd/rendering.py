@@ -166,22 +166,50 @@ def _render_rays_train(model, rays_o, rays_d, hits_t, **kwargs):
         sigmas.contiguous(), rgbs.contiguous(), normals_pred.contiguous(), sems.contiguous(),
         results['deltas'], results['ts'], rays_a, T_threshold, classes)
 
+    rgb_bg = None  # black background (synthetic scenes): rgb + 0*(1-opacity) is rgb, skip the ops
     if kwargs.get('use_skybox', False):
         rgb_bg = model.forward_skybox(rays_d)
     elif exp_step_factor != 0 and kwargs.get('random_bg', False):
         rgb_bg = torch.rand(3, device=rays_o.device)
-    else:
-        rgb_bg = torch.zeros(3, device=rays_o.device)
-    results['rgb'] = results['rgb'] + rgb_bg * (1 - results['opacity'])[:, None]
+    if rgb_bg is not None:
+        results['rgb'] = results['rgb'] + rgb_bg * (1 - results['opacity'])[:, None]
 
     # Ref-NeRF normal regularisers (rendering.py:243-249)
-    normals_diff = (normals_raw - normals_pred) ** 2
-    dirs_n = F.normalize(dirs, p=2, dim=-1, eps=1e-6)
-    normals_ori = torch.clamp(torch.sum(normals_raw * dirs_n, dim=-1), min=0.) ** 2
+    normals_diff, normals_ori = _RefLossInputs.apply(normals_raw, normals_pred, dirs)
     results['Ro'], results['Rp'] = RefLoss.apply(
-        sigmas.detach().contiguous(), normals_diff.contiguous(), normals_ori.contiguous(),
+        sigmas.detach().contiguous(), normals_diff, normals_ori,
         results['deltas'], results['ts'], rays_a, T_threshold)
     return results
+
+
+class _RefLossInputs(torch.autograd.Function):
+    """normals_diff = (n_raw - n_pred)^2 (N,3), normals_ori = clamp(<n_raw, normalize(dir)>, 0)^2 (N)
+    in one launch (the reference spends ~12 elementwise launches here, rendering.py:243-245)."""
+
+    @staticmethod
+    def forward(ctx, normals_raw, normals_pred, dirs):
+        normals_raw, normals_pred, dirs = normals_raw.contiguous(), normals_pred.contiguous(), dirs.contiguous()
+        n = normals_raw.shape[0]
+        ndiff = torch.empty(n, 3, dtype=torch.float32, device=dirs.device)
+        nori = torch.empty(n, dtype=torch.float32, device=dirs.device)
+        call("refloss_inputs", normals_raw, normals_pred, dirs, n, ndiff, nori)
+        ctx.save_for_backward(normals_raw, normals_pred, dirs)
+        return ndiff, nori
+
+    @staticmethod
+    def backward(ctx, g_diff, g_ori):
+        normals_raw, normals_pred, dirs = ctx.saved_tensors
+        e = normals_raw - normals_pred
+        d_raw = d_pred = None
+        if g_diff is not None:
+            d_raw = 2 * e * g_diff
+            d_pred = -d_raw
+        if g_ori is not None:
+            dn = F.normalize(dirs, p=2, dim=-1, eps=1e-6)
+            dot = torch.clamp(torch.sum(normals_raw * dn, dim=-1, keepdim=True), min=0.)
+            t = 2 * dot * dn * g_ori[:, None]
+            d_raw = t if d_raw is None else d_raw + t
+        return d_raw, d_pred, None
 
 
 # name-mangled aliases the reference module exposes internally

@@ -24,7 +24,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import call
-from .losses import NeRFLoss
+from .losses import FusedNeRFLoss, NeRFLoss
 from .rendering import MAX_SAMPLES, render
 
 _f32 = torch.float32
@@ -119,6 +119,7 @@ class NGPTrainer:
         self.density_threshold = density_threshold
         self.render_kwargs = dict(render_kwargs or {})
         self.loss_fn = NeRFLoss()
+        self.fused_loss = True   # default recipe (rgb + opacity + distortion); False -> NeRFLoss module
         self.warmup_steps = 256
         self.update_interval = 16
         self.global_step = 0
@@ -193,8 +194,14 @@ class NGPTrainer:
                                       warmup=self.global_step < self.warmup_steps)
         results = render(model, rays_o, rays_d, exp_step_factor=self.exp_step_factor,
                          num_classes=self.num_classes, **self.render_kwargs)
-        loss_d = self.loss_fn(results, {"rgb": rgb_gt})
-        loss = sum(lo.mean() for lo in loss_d.values())
+        if self.fused_loss:
+            # same value and gradients as sum(term.mean()) over NeRFLoss's default terms
+            loss, *_terms = FusedNeRFLoss.apply(results["rgb"], results["opacity"], results["ws"], results["deltas"],
+                                                results["ts"], results["rays_a"], rgb_gt, self.loss_fn.lambda_opa,
+                                                self.loss_fn.lambda_distortion)
+        else:
+            loss_d = self.loss_fn(results, {"rgb": rgb_gt})
+            loss = sum(lo.mean() for lo in loss_d.values())
         loss.backward()
         self.optimizer_step()
         return loss.detach(), results

@@ -643,3 +643,55 @@ def test_differentiable_normals_h4(ngp):
             p.add_(eps * dd)
     fd = (lp - lm) / (2 * eps)
     assert abs(fd - analytic) < 0.05 * max(abs(fd), abs(analytic), 1.0), (fd, analytic)
+
+
+def test_fused_loss_matches_nerfloss(ngp):
+    from ngp_amd.losses import FusedNeRFLoss, NeRFLoss
+    g = rng(240)
+    rays_a, n = make_segments(500, 40, seed=241)
+    nr = len(rays_a)
+    ws0 = (g.random(n) * 0.05).astype(np.float32)
+    deltas = (0.002 + 0.01 * g.random(n)).astype(np.float32)
+    ts = np.zeros(n, np.float32)
+    for _, s, c in rays_a:
+        ts[s:s + c] = 0.4 + np.cumsum(deltas[s:s + c])
+    gt = T(g.random((nr, 3)).astype(np.float32))
+    outs = []
+    for fused in (False, True):
+        rgb = T(g.random((nr, 3)).astype(np.float32) if not outs else outs[0][3]).requires_grad_(True)
+        op = T((g.random(nr) * 0.98 + 0.01).astype(np.float32) if not outs else outs[0][4]).requires_grad_(True)
+        ws = T(ws0).requires_grad_(True)
+        res = {"rgb": rgb, "opacity": op, "ws": ws, "deltas": T(deltas), "ts": T(ts), "rays_a": T(rays_a)}
+        if fused:
+            loss, *_ = FusedNeRFLoss.apply(rgb, op, ws, res["deltas"], res["ts"], res["rays_a"], gt, 2e-4, 3e-4)
+        else:
+            loss = sum(v.mean() for v in NeRFLoss()(res, {"rgb": gt}).values())
+        grads = torch.autograd.grad(loss, [rgb, op, ws])
+        outs.append((float(loss), [N(x) for x in grads], None, N(rgb), N(op)))
+    assert abs(outs[0][0] - outs[1][0]) < 1e-6 * max(1.0, abs(outs[0][0]))
+    for a, b in zip(outs[0][1], outs[1][1]):
+        close(b, a, 1e-4, 1e-9)
+
+
+def test_neg_normalize_and_refloss_inputs(ngp):
+    from ngp_amd.networks import _NegNormalize
+    from ngp_amd.rendering import _RefLossInputs
+    F_ = torch.nn.functional
+    g = rng(250)
+    x = T(g.normal(size=(1000, 3)).astype(np.float32))
+    x[0] = 0.0
+    xr = x.clone().requires_grad_(True)
+    y = _NegNormalize.apply(xr, None)
+    ref = -F_.normalize(x, p=2, dim=-1, eps=1e-6)
+    close(N(y), N(ref), 1e-6, 1e-7)
+    w = T(g.normal(size=(1000, 3)).astype(np.float32))
+    (gx,) = torch.autograd.grad(y, xr, w)
+    xr2 = x.clone().requires_grad_(True)
+    (gref,) = torch.autograd.grad(-F_.normalize(xr2, p=2, dim=-1, eps=1e-6), xr2, w)
+    close(N(gx)[1:], N(gref)[1:], 1e-4, 1e-5)
+    sc = T(np.array([2.0, 0.5, 1.5], np.float32))
+    close(N(_NegNormalize.apply(x, sc)), N(-F_.normalize(x * sc, dim=-1, eps=1e-6)), 1e-6, 1e-7)
+    n_raw, n_pred, dirs = (T(g.normal(size=(1000, 3)).astype(np.float32)) for _ in range(3))
+    nd, no = _RefLossInputs.apply(n_raw, n_pred, dirs)
+    close(N(nd), N((n_raw - n_pred) ** 2), 1e-6, 1e-7)
+    close(N(no), N(torch.clamp((n_raw * F_.normalize(dirs, dim=-1, eps=1e-6)).sum(-1), min=0.) ** 2), 1e-5, 1e-6)
