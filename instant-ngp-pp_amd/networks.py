@@ -87,7 +87,7 @@ def _side_stream(dev):
 
 
 def _mlp2_backward(d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, ld_in, n_in, W1, ldw1, dW1, dW2,
-                   db1, db2, dx, ld_dx, dx_cols, w1_col0, accumulate):
+                   db1, db2, dx, ld_dx, dx_cols, w1_col0, accumulate, before_products=None):
     """Backward of a 2-layer MLP (x_in -> H hidden with act1 -> n_out with act2) on the library:
     dz2/dz1 by the fused hidden-backward kernel, three MFMA/VALU products for dW2, dW1 and dx.
     dx receives dz1 . W1[:, w1_col0 : w1_col0+dx_cols] (the input columns that need a gradient)."""
@@ -98,7 +98,18 @@ def _mlp2_backward(d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, l
     call("mlp_hidden_bwd", d_out, d_out.stride(0), out, ld_out, act2, W2, H, hidden, H, act1, n, H, n_out,
          dz2, dz2.shape[1], dz1, H)
     call("linear_bwd_weight", dz2, dz2.shape[1], hidden, H, n, H, n_out, dW2, H, db2)
-    call("linear_bwd_weight", dz1, H, x_in, ld_in, n, n_in, H, dW1, ldw1, db1)
+    if before_products is not None:
+        before_products()
+    if n_in > 128 and n_in % 128 <= 32:
+        # 128 + remainder columns: a second launch with 128x32 tiles instead of a mostly empty
+        # 128x128 tile (rgb_net's first layer is 128 x 144)
+        call("linear_bwd_weight", dz1, H, x_in, ld_in, n, 128, H, dW1, ldw1, db1)
+        rem = n_in - 128
+        x_rem = x_in[:, 128:] if x_in.dim() == 2 else x_in
+        call("linear_bwd_weight", dz1, H, x_rem, ld_in, n, rem, H, dW1[128:] if dW1.dim() == 1 else dW1[:, 128:],
+             ldw1, None)
+    else:
+        call("linear_bwd_weight", dz1, H, x_in, ld_in, n, n_in, H, dW1, ldw1, db1)
     if dx is not None:
         call("linear_bwd_input", dz1, H, W1[w1_col0:] if W1.dim() == 1 else W1, ldw1, n, dx_cols, H, dx, ld_dx,
              1 if accumulate else 0)
@@ -115,10 +126,13 @@ class _NegNormalize(Function):
         call("neg_normalize", x, 3, scale3, x.shape[0], y)
         if scale3 is None:
             ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)
         return y
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None
         (x,) = ctx.saved_tensors
         dx = torch.empty_like(x)
         call("neg_normalize_bwd", x, 3, g.contiguous(), x.shape[0], dx)
@@ -226,8 +240,8 @@ class _FieldFn(Function):
         if d_rgb is not None:
             g_rgbp = torch.zeros_like(rgb_p)
             dfeat_rgb = torch.empty(n, W_cols, dtype=_f32, device=dev)
-            _mlp2_backward(d_rgb.contiguous(), rgb_o, 3, model.rgb_net.output_activation, rgb_p[128 * Kp:], a_r, 128, _RELU, 3,
-                           rgb_in, Kp, Kp, rgb_p, Kp, g_rgbp, g_rgbp[128 * Kp:], None, None,
+            _mlp2_backward(d_rgb.contiguous(), rgb_o, 3, model.rgb_net.output_activation, rgb_p[128 * Kp:], a_r, 128,
+                           _RELU, 3, rgb_in, Kp, Kp, rgb_p, Kp, g_rgbp, g_rgbp[128 * Kp:], None, None,
                            dfeat_rgb, W_cols, W_cols, 16, False)
         for d_o, p, a_h, out, n_out, slot in ((d_np, nrm_p, a_n, np_o, 3, "nrm"), (d_sem, sem_p, a_s, sem_o, C, "sem")):
             if d_o is None:
@@ -243,31 +257,36 @@ class _FieldFn(Function):
                 g_nrm = g_p
             else:
                 g_sem = g_p
-        if dfeat_rgb is not None:
-            if need[9]:
-                buf = getattr(re, "grad_buffer", None)
-                if buf is None:
-                    g_rgbt = torch.zeros_like(rgb_table)
-                    buf = g_rgbt
-                # The colour-table scatter is bound by memory-side atomics, the density head's
-                # backward that follows by MFMA/LDS: run the scatter on a side stream so the two
-                # overlap (joined at the end of backward).
-                side = _side_stream(dev) if _OVERLAP else None
-                if side is not None:
-                    main = torch.cuda.current_stream()
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        call("grid_bwd_param", re.desc, xn, dfeat_rgb, W_cols, n, buf)
-                        cb = getattr(re, "on_grad_ready", None)
-                        if cb is not None:
-                            cb()
-                    dfeat_rgb.record_stream(side)
-                    xn.record_stream(side)
-                else:
+
+        # The colour-table scatter is bound by memory-side atomics; the density head's MFMA products
+        # are not.  The scatter is therefore forked onto a side stream right before those products
+        # (after the head's bandwidth-bound elementwise stage, which would only fight it for HBM) and
+        # joined at the end of backward.
+        forked = False
+
+        def colour_scatter():
+            nonlocal g_rgbt, forked
+            if dfeat_rgb is None or not need[9]:
+                return
+            buf = getattr(re, "grad_buffer", None)
+            if buf is None:
+                g_rgbt = torch.zeros_like(rgb_table)
+                buf = g_rgbt
+            cb = getattr(re, "on_grad_ready", None)
+            if _OVERLAP and d_sig is not None:
+                side = _side_stream(dev)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
                     call("grid_bwd_param", re.desc, xn, dfeat_rgb, W_cols, n, buf)
-                    cb = getattr(re, "on_grad_ready", None)
                     if cb is not None:
                         cb()
+                forked = True
+            else:
+                call("grid_bwd_param", re.desc, xn, dfeat_rgb, W_cols, n, buf)
+                if cb is not None:
+                    cb()
+
+        if dfeat_rgb is not None:
             if E and need[3]:
                 g_emb = dfeat_rgb[:, 128:]
             if need[1]:
@@ -281,7 +300,8 @@ class _FieldFn(Function):
             g_b2 = torch.zeros(1, dtype=_f32, device=dev)
             dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
             _mlp2_backward(d_sig.contiguous().view(n, 1), sig, 1, _SOFTPLUS, W2, a1, 128, _SOFTPLUS, 1,
-                           feat, 128, 128, W1, 128, g_W1, g_W2, g_b1, g_b2, dfeat, 128, 128, 0, False)
+                           feat, 128, 128, W1, 128, g_W1, g_W2, g_b1, g_b2, dfeat, 128, 128, 0, False,
+                           before_products=colour_scatter)
             if need[4]:
                 buf = getattr(xe, "grad_buffer", None)
                 if buf is None:
@@ -295,9 +315,11 @@ class _FieldFn(Function):
                 gx2 = torch.empty(n, 3, dtype=_f32, device=dev)
                 call("grid_bwd_input", xe.desc, xyz_table, xn, dfeat, 128, n, gx2)
                 g_x = gx2 if g_x is None else g_x + gx2
+        else:
+            colour_scatter()
         if g_x is not None:
             g_x = g_x / span
-        if _OVERLAP and dfeat_rgb is not None and need[9]:
+        if forked:
             torch.cuda.current_stream().wait_stream(_side_stream(dev))
         return (None, g_x, None, g_emb, g_xyz, g_W1, g_b1, g_W2, g_b2, g_rgbt, g_rgbp, g_nrm, g_sem)
 
