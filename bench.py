@@ -192,12 +192,25 @@ def main():
                 kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms)}
         grid_names = [k for k in kern if k.startswith("grid")]
         dom = max(grid_names, key=lambda k: kern[k]["total_ms"])
+        # HBM traffic per launch from the committed rocprofv3 --pmc passes over this same command
+        # (profiles/r01_pmc_traffic.json, tools/pmc_traffic.py): WRITE_SIZE is exact for fp32 atomics,
+        # FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B; calibrated here on the known
+        # 512 B/sample dL_dy stream, which it reports as 268 B).
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))[dom]
+            traffic = (2 * pmc["fetch_bytes_per_sample"] + pmc["write_bytes_per_sample"]) * kern[dom]["avg_samples"]
+        except Exception:
+            pass
         roofline = {
             "kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+            "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
             "avg_launch_ms": kern[dom]["avg_ms"], "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE[dom],
-            "note": "fp32 global atomics are bounded by ~1.3 TB/s of added bytes on MI355X "
-                    "(MI355X_MICROARCH.md), below the 8 TB/s HBM peak used for frac" if dom == "grid_bwd_param" else "",
+            "note": "achieved = algorithmic bytes (4096 B of fp32 atomic adds + 512 B read per sample) / launch time; "
+                    "the kernel is bound by the memory-side atomic request rate (~22 G requests/s measured, "
+                    "~1.3 TB/s of added bytes in ideal shapes per MI355X_MICROARCH.md), not by the 8 TB/s used for "
+                    "frac; run merging + zero skipping + x-pair coalescing cut the real traffic to `traffic` bytes"
+                    if dom == "grid_bwd_param" else "",
         }
         out = {
             "metric": "train rays/sec", "value": rays_total / elapsed, "unit": "rays/s",

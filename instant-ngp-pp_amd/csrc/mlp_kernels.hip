@@ -11,6 +11,7 @@
 // and B[k=l>>5][j=l&31]; C/D is col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5).
 // Layers with n_out <= 4 (the density head, networks.py:57) use VALU kernels instead.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -639,10 +640,11 @@ int ngp_linear_bwd_weight(const float* dz, int64_t lddz, const float* x, int64_t
     p.A = dz; p.lda = lddz; p.B = x; p.ldb = ldx; p.C = dW; p.ldc = ldw;
     p.M = n_out; p.N = n_in; p.K = n; p.act = 0; p.bias_grad = db;
     p.vecA = aligned16(dz) && (lddz % 4 == 0); p.vecB = aligned16(x) && (ldx % 4 == 0);
-    // split the sample dimension so that ~1024 workgroups are in flight
+    // split the sample dimension so that one full wave of workgroups (3 per CU) is in flight
     const bool big_m = n_out > 32, big_n = n_in > 32;
     const int64_t tiles = (int64_t)ngp_blocks(n_out, big_m ? 128 : 32) * ngp_blocks(n_in, big_n ? 128 : 32);
-    int64_t splits = 1024 / (tiles > 0 ? tiles : 1);
+    static const int target_blocks = getenv("NGP_WGRAD_BLOCKS") ? atoi(getenv("NGP_WGRAD_BLOCKS")) : 768; // 3 workgroups per CU x 256 CUs
+    int64_t splits = target_blocks / (tiles > 0 ? tiles : 1);
     if (splits < 1) splits = 1;
     int64_t chunk = (n + splits - 1) / splits;
     chunk = (chunk + BK - 1) / BK * BK;
