@@ -35,9 +35,10 @@ class GradBuckets:
     agnostic: the gloo CPU tests drive this class directly).
 
     all-reduce mode   : reduce_bucket(i) sums bucket i over the ranks (async), wait() joins.
-    sharded mode      : reduce_scatter_bucket(i) leaves rank r with the summed slice r of bucket i
-                        (in place, RCCL reduce-scatter), all_gather_bucket(i, flat_param) publishes
-                        each rank's updated parameter slice to everyone (in place all-gather).
+    sharded mode      : reduce_scatter_bucket(i, out) gives rank r the summed slice r of bucket i
+                        (RCCL reduce-scatter into the rank's own shard buffer),
+                        all_gather_bucket(i, flat_param, shard) publishes each rank's updated
+                        parameter slice to everyone.
     Buckets must be a multiple of world*4 elements long in sharded mode (the trainer pads).
     """
 
@@ -69,30 +70,31 @@ class GradBuckets:
         lo, hi = self.bounds[i], self.bounds[i + 1]
         self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def reduce_scatter_bucket(self, i):
+    def reduce_scatter_bucket(self, i, out):
+        """out (own buffer, 1/world of the bucket) <- this rank's slice of the bucket summed over ranks"""
         if self.world == 1:
             return
         lo, hi = self.bounds[i], self.bounds[i + 1]
         if self._native_rs():
-            a, b = self.shard_range(i)
-            self.works.append(dist.reduce_scatter_tensor(self.flat[a:b], self.flat[lo:hi], op=dist.ReduceOp.SUM,
+            self.works.append(dist.reduce_scatter_tensor(out, self.flat[lo:hi], op=dist.ReduceOp.SUM,
                                                          group=self.group, async_op=True))
-        else:  # gloo has no reduce-scatter: all-reduce, the owner simply uses its slice
-            self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                              async_op=True))
+        else:  # gloo has no reduce-scatter: all-reduce, then the owner copies its slice out
+            a, b = self.shard_range(i)
+            w = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w.wait()
+            out.copy_(self.flat[a:b])
 
-    def all_gather_bucket(self, i, flat_param):
+    def all_gather_bucket(self, i, flat_param, shard):
+        """flat_param[bucket i] <- concatenation over ranks of `shard` (own buffer)"""
         if self.world == 1:
             return
         lo, hi = self.bounds[i], self.bounds[i + 1]
-        a, b = self.shard_range(i)
         if self._native_rs():
-            self.works.append(dist.all_gather_into_tensor(flat_param[lo:hi], flat_param[a:b], group=self.group,
-                                                          async_op=True))
+            self.works.append(dist.all_gather_into_tensor(flat_param[lo:hi], shard, group=self.group, async_op=True))
         else:
             s = (hi - lo) // self.world
             views = [flat_param[lo + r * s: lo + (r + 1) * s] for r in range(self.world)]
-            self.works.append(dist.all_gather(views, flat_param[a:b].clone(), group=self.group, async_op=True))
+            self.works.append(dist.all_gather(views, shard, group=self.group, async_op=True))
 
     def wait(self):
         for w in self.works:
@@ -164,6 +166,9 @@ class NGPTrainer:
             self.shards = [self.buckets.shard_range(i) for i in range(len(self.buckets.bounds) - 1)]
             self.exp_avg = [torch.zeros(b - a, dtype=_f32, device=dev) for a, b in self.shards]
             self.exp_avg_sq = [torch.zeros(b - a, dtype=_f32, device=dev) for a, b in self.shards]
+            # master copy of this rank's parameter slices and the landing buffers of the reduce-scatter
+            self.param_shard = [self.flat_param[a:b].clone() for a, b in self.shards]
+            self.grad_shard = [torch.zeros(b - a, dtype=_f32, device=dev) for a, b in self.shards]
         else:
             self.exp_avg = torch.zeros(total, dtype=_f32, device=dev)
             self.exp_avg_sq = torch.zeros(total, dtype=_f32, device=dev)
@@ -175,7 +180,163 @@ class NGPTrainer:
         # bucket 0's reduce-scatter is fired from the colour encoder's backward (overlaps the rest)
         self.hooked0 = bool(hasattr(self.model, "rgb_encoder") and self.sharded and b0)
         if self.hooked0:
-            self.model.rgb_encoder.on_grad_ready = lambda: self.buckets.reduce_scatter_bucket(0)
+            self.model.rgb_encoder.on_grad_ready = lambda: self.buckets.reduce_scatter_bucket(0, self.grad_shard[0])
+
+    # ------------------------------------------------------------------ schedule
+    def lr_at(self, epoch):
+        eta_min = self.base_lr / 30
+        return eta_min + (self.base_lr - eta_min) * (1 + math.cos(math.pi * epoch / self.num_epochs)) / 2
+
+    @property
+    def lr(self):
+        return self.lr_at(min(self.global_step // self.steps_per_epoch, self.num_epochs))
+
+    def step(self, rays_o, rays_d, rgb_gt):
+        """one training step on this rank's ray batch; returns (loss tensor, results dict)"""
+        model = self.model
+        if self.global_step % self.update_interval == 0:
+            model.update_density_grid(self.density_threshold * MAX_SAMPLES / 3 ** 0.5,
+                                      warmup=self.global_step < self.warmup_steps)
+        results = render(model, rays_o, rays_d, exp_step_factor=self.exp_step_factor,
+                         num_classes=self.num_classes, **self.render_kwargs)
+        if self.fused_loss:
+            # same value and gradients as sum(term.mean()) over NeRFLoss's default terms
+            loss, *_terms = FusedNeRFLoss.apply(results["rgb"], results["opacity"], results["ws"], results["deltas"],
+                                                results["ts"], results["rays_a"], rgb_gt, self.loss_fn.lambda_opa,
+                                                self.loss_fn.lambda_distortion)
+        else:
+            loss_d = self.loss_fn(results, {"rgb": rgb_gt})
+            loss = sum(lo.mean() for lo in loss_d.values())
+        loss.backward()
+        self.optimizer_step()
+        return loss.detach(), results
+
+    def optimizer_step(self):
+        world = self.buckets.world
+        self.global_step += 1
+        # lr of the epoch this step belongs to (the scheduler ticks at epoch boundaries)
+        lr = self.lr_at(min((self.global_step - 1) // self.steps_per_epoch, self.num_epochs))
+        if not self.sharded:
+            # clip + Adam stream 6.4 GB and touch no ray data: run them on a side stream so the next
+            # step's ray generation / AABB / marcher (latency bound, 128 waves) overlap; the field
+            # waits on `_params_ready` before it reads a parameter.
+            n = self.flat_grad.numel()
+            main = torch.cuda.current_stream()
+            side = self._opt_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.scalars.zero_()
+                call("sumsq", self.flat_grad, n, self.scalars[0:1])
+                call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2])
+                call("adam_step", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, n, float(lr), 0.9,
+                     0.999, 1e-8, 0.0, self.global_step, self.scalars[1:2], 1)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            self.model._params_ready = ev
+            return
+        self.scalars.zero_()
+        # sharded: bucket 0's reduce-scatter was issued from the colour encoder's backward
+        nb = len(self.buckets.bounds) - 1
+        for i in range(1 if self.hooked0 else 0, nb):
+            self.buckets.reduce_scatter_bucket(i, self.grad_shard[i])
+        self.buckets.wait()
+        self.flat_grad.zero_()              # all contributions are in the shard buffers now
+        for g in self.grad_shard:           # global grad norm = sqrt(sum over ranks of shard sums)
+            call("sumsq", g, g.numel(), self.scalars[0:1])
+        dist.all_reduce(self.scalars[0:1], op=dist.ReduceOp.SUM, group=self.group)
+        call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0 / world, self.scalars[1:2])
+        for i in range(nb):
+            call("adam_step", self.param_shard[i], self.grad_shard[i], self.exp_avg[i], self.exp_avg_sq[i],
+                 self.grad_shard[i].numel(), float(lr), 0.9, 0.999, 1e-8, 0.0, self.global_step, self.scalars[1:2], 0)
+        for i in range(nb):
+            self.buckets.all_gather_bucket(i, self.flat_param, self.param_shard[i])
+        self.buckets.wait()
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+def shard_seed(base_seed, rank):
+    """per-rank decorrelated ray sampling (the reference leaves this to
+    DataLoader worker seeding)"""
+    return int(base_seed) + int(rank)
+
+
+class NGPTrainer:
+    def __init__(self, model, lr=1e-2, num_epochs=20, steps_per_epoch=1000, clip_norm=50.0,
+                 exp_step_factor=0.0, num_classes=7, density_threshold=0.01, render_kwargs=None, group=None):
+        self.model = model
+        self.base_lr = lr
+        self.num_epochs = num_epochs
+        self.steps_per_epoch = steps_per_epoch
+        self.clip_norm = clip_norm
+        self.exp_step_factor = exp_step_factor
+        self.num_classes = num_classes
+        self.density_threshold = density_threshold
+        self.render_kwargs = dict(render_kwargs or {})
+        self.loss_fn = NeRFLoss()
+        self.fused_loss = True   # default recipe (rgb + opacity + distortion); False -> NeRFLoss module
+        self.warmup_steps = 256
+        self.update_interval = 16
+        self.global_step = 0
+        self.group = group
+        self._flatten()
+        self._opt_stream = torch.cuda.Stream(device=self.flat_param.device) if self.flat_param.is_cuda else None
+
+    # ------------------------------------------------------------------ flat parameter store
+    def _flatten(self):
+        named = [(n, p) for n, p in self.model.named_parameters() if p.numel() > 0]
+        order = {"rgb_encoder.params": 0, "xyz_encoder.params": 1}
+        named.sort(key=lambda np_: order.get(np_[0], 2))
+        self.names = [n for n, _ in named]
+        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        quantum = 4 * world   # every slice 16-byte aligned; every bucket divisible by the world size
+        sizes = [(p.numel() + 3) // 4 * 4 for _, p in named]
+        if named[0][0] == "rgb_encoder.params":           # bucket 0 = the colour table alone
+            sizes[0] = (sizes[0] + quantum - 1) // quantum * quantum
+        rest = sum(sizes[1:]) if named[0][0] == "rgb_encoder.params" else sum(sizes)
+        sizes[-1] += (quantum - rest % quantum) % quantum
+        total = sum(sizes)
+        dev = named[0][1].device
+        self.sharded = world > 1
+        self.flat_param = torch.zeros(total, dtype=_f32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=_f32, device=dev)
+        self.scalars = torch.zeros(2, dtype=_f32, device=dev)  # [sum of squares, clip coefficient]
+        off = 0
+        self.slices = {}
+        for (n, p), sz in zip(named, sizes):
+            view = self.flat_param[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            self.slices[n] = (off, p.numel())
+            off += sz
+        # bucket 0 = rgb table, bucket 1 = everything else
+        b0 = sizes[0] if named[0][0] == "rgb_encoder.params" else 0
+        self.buckets = GradBuckets(self.flat_grad, [0, b0, total] if b0 else [0, total], group=self.group)
+        # Adam state: whole buffer on one GPU; with N ranks each rank keeps (and updates) only its
+        # 1/N slice of every bucket — reduce-scatter gradients, Adam on the slice, all-gather params
+        if self.sharded:
+            self.shards = [self.buckets.shard_range(i) for i in range(len(self.buckets.bounds) - 1)]
+            self.exp_avg = [torch.zeros(b - a, dtype=_f32, device=dev) for a, b in self.shards]
+            self.exp_avg_sq = [torch.zeros(b - a, dtype=_f32, device=dev) for a, b in self.shards]
+            # master copy of this rank's parameter slices and the landing buffers of the reduce-scatter
+            self.param_shard = [self.flat_param[a:b].clone() for a, b in self.shards]
+            self.grad_shard = [torch.zeros(b - a, dtype=_f32, device=dev) for a, b in self.shards]
+        else:
+            self.exp_avg = torch.zeros(total, dtype=_f32, device=dev)
+            self.exp_avg_sq = torch.zeros(total, dtype=_f32, device=dev)
+        # scatter kernels accumulate directly into the flat gradient (see tinycudann._GridFwd)
+        for enc_name in ("rgb_encoder", "xyz_encoder"):
+            enc = getattr(self.model, enc_name, None)
+            if enc is not None:
+                enc.grad_buffer = enc.params.grad
+        # bucket 0's reduce-scatter is fired from the colour encoder's backward (overlaps the rest)
+        self.hooked0 = bool(hasattr(self.model, "rgb_encoder") and self.sharded and b0)
+        if self.hooked0:
+            self.model.rgb_encoder.on_grad_ready = lambda: self.buckets.reduce_scatter_bucket(0, self.grad_shard[0])
 
     # ------------------------------------------------------------------ schedule
     def lr_at(self, epoch):
@@ -261,6 +422,9 @@ class NGPTrainer:
         if self.buckets.world == 1:
             return
         dist.broadcast(self.flat_param, src, group=self.group)
+        if self.sharded:
+            for ps, (a, b) in zip(self.param_shard, self.shards):
+                ps.copy_(self.flat_param[a:b])
         for name in ("density_grid", "density_bitfield"):
             if hasattr(self.model, name):
                 dist.broadcast(getattr(self.model, name), src, group=self.group)

@@ -154,13 +154,30 @@ def _bucket_worker(rank, world, port, q):
     g = torch.Generator().manual_seed(shard_seed(20220806, rank))
     flat = torch.randn(1000, generator=g)
     mine = flat.clone()
-    b = GradBuckets(flat, [0, 600, 1000])
-    b.reduce_bucket(0)       # fired from the rgb encoder's backward in the trainer
-    b.reduce_bucket(1)       # fired after backward
-    b.wait()
     gathered = [torch.zeros(1000) for _ in range(world)]
     dist.all_gather(gathered, mine)
-    q.put((rank, torch.allclose(flat, sum(gathered), atol=1e-6), float(mine[0])))
+    total = sum(gathered)
+    b = GradBuckets(flat, [0, 600, 1000])
+    # sharded path: each rank ends up with its slice of the summed bucket in its own buffer ...
+    shards = [torch.zeros(300), torch.zeros(200)]
+    b.reduce_scatter_bucket(0, shards[0])   # fired from the rgb encoder's backward in the trainer
+    b.reduce_scatter_bucket(1, shards[1])   # fired after backward
+    b.wait()
+    ok = all(torch.allclose(shards[i], total[slice(*b.shard_range(i))], atol=1e-6) for i in range(2))
+    # ... updates it, and the all-gather rebuilds the full parameter vector on every rank
+    params = torch.zeros(1000)
+    for i in range(2):
+        b.all_gather_bucket(i, params, shards[i] * 0.5)
+    b.wait()
+    ok = ok and torch.allclose(params, total * 0.5, atol=1e-6)
+    # plain all-reduce mode
+    flat2 = mine.clone()
+    b2 = GradBuckets(flat2, [0, 600, 1000])
+    b2.reduce_bucket(0)
+    b2.reduce_bucket(1)
+    b2.wait()
+    ok = ok and torch.allclose(flat2, total, atol=1e-6)
+    q.put((rank, bool(ok), float(mine[0])))
     dist.destroy_process_group()
 
 
