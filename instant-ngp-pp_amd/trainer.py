@@ -252,161 +252,6 @@ class NGPTrainer:
             self.buckets.all_gather_bucket(i, self.flat_param, self.param_shard[i])
         self.buckets.wait()
 
-    def wait(self):
-        for w in self.works:
-            w.wait()
-        self.works = []
-
-
-def shard_seed(base_seed, rank):
-    """per-rank decorrelated ray sampling (the reference leaves this to
-    DataLoader worker seeding)"""
-    return int(base_seed) + int(rank)
-
-
-class NGPTrainer:
-    def __init__(self, model, lr=1e-2, num_epochs=20, steps_per_epoch=1000, clip_norm=50.0,
-                 exp_step_factor=0.0, num_classes=7, density_threshold=0.01, render_kwargs=None, group=None):
-        self.model = model
-        self.base_lr = lr
-        self.num_epochs = num_epochs
-        self.steps_per_epoch = steps_per_epoch
-        self.clip_norm = clip_norm
-        self.exp_step_factor = exp_step_factor
-        self.num_classes = num_classes
-        self.density_threshold = density_threshold
-        self.render_kwargs = dict(render_kwargs or {})
-        self.loss_fn = NeRFLoss()
-        self.fused_loss = True   # default recipe (rgb + opacity + distortion); False -> NeRFLoss module
-        self.warmup_steps = 256
-        self.update_interval = 16
-        self.global_step = 0
-        self.group = group
-        self._flatten()
-        self._opt_stream = torch.cuda.Stream(device=self.flat_param.device) if self.flat_param.is_cuda else None
-
-    # ------------------------------------------------------------------ flat parameter store
-    def _flatten(self):
-        named = [(n, p) for n, p in self.model.named_parameters() if p.numel() > 0]
-        order = {"rgb_encoder.params": 0, "xyz_encoder.params": 1}
-        named.sort(key=lambda np_: order.get(np_[0], 2))
-        self.names = [n for n, _ in named]
-        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
-        quantum = 4 * world   # every slice 16-byte aligned; every bucket divisible by the world size
-        sizes = [(p.numel() + 3) // 4 * 4 for _, p in named]
-        if named[0][0] == "rgb_encoder.params":           # bucket 0 = the colour table alone
-            sizes[0] = (sizes[0] + quantum - 1) // quantum * quantum
-        rest = sum(sizes[1:]) if named[0][0] == "rgb_encoder.params" else sum(sizes)
-        sizes[-1] += (quantum - rest % quantum) % quantum
-        total = sum(sizes)
-        dev = named[0][1].device
-        self.sharded = world > 1
-        self.flat_param = torch.zeros(total, dtype=_f32, device=dev)
-        self.flat_grad = torch.zeros(total, dtype=_f32, device=dev)
-        self.scalars = torch.zeros(2, dtype=_f32, device=dev)  # [sum of squares, clip coefficient]
-        off = 0
-        self.slices = {}
-        for (n, p), sz in zip(named, sizes):
-            view = self.flat_param[off:off + p.numel()].view_as(p)
-            view.copy_(p.data)
-            p.data = view
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-            self.slices[n] = (off, p.numel())
-            off += sz
-        # bucket 0 = rgb table, bucket 1 = everything else
-        b0 = sizes[0] if named[0][0] == "rgb_encoder.params" else 0
-        self.buckets = GradBuckets(self.flat_grad, [0, b0, total] if b0 else [0, total], group=self.group)
-        # Adam state: whole buffer on one GPU; with N ranks each rank keeps (and updates) only its
-        # 1/N slice of every bucket — reduce-scatter gradients, Adam on the slice, all-gather params
-        if self.sharded:
-            self.shards = [self.buckets.shard_range(i) for i in range(len(self.buckets.bounds) - 1)]
-            self.exp_avg = [torch.zeros(b - a, dtype=_f32, device=dev) for a, b in self.shards]
-            self.exp_avg_sq = [torch.zeros(b - a, dtype=_f32, device=dev) for a, b in self.shards]
-            # master copy of this rank's parameter slices and the landing buffers of the reduce-scatter
-            self.param_shard = [self.flat_param[a:b].clone() for a, b in self.shards]
-            self.grad_shard = [torch.zeros(b - a, dtype=_f32, device=dev) for a, b in self.shards]
-        else:
-            self.exp_avg = torch.zeros(total, dtype=_f32, device=dev)
-            self.exp_avg_sq = torch.zeros(total, dtype=_f32, device=dev)
-        # scatter kernels accumulate directly into the flat gradient (see tinycudann._GridFwd)
-        for enc_name in ("rgb_encoder", "xyz_encoder"):
-            enc = getattr(self.model, enc_name, None)
-            if enc is not None:
-                enc.grad_buffer = enc.params.grad
-        # bucket 0's reduce-scatter is fired from the colour encoder's backward (overlaps the rest)
-        self.hooked0 = bool(hasattr(self.model, "rgb_encoder") and self.sharded and b0)
-        if self.hooked0:
-            self.model.rgb_encoder.on_grad_ready = lambda: self.buckets.reduce_scatter_bucket(0, self.grad_shard[0])
-
-    # ------------------------------------------------------------------ schedule
-    def lr_at(self, epoch):
-        eta_min = self.base_lr / 30
-        return eta_min + (self.base_lr - eta_min) * (1 + math.cos(math.pi * epoch / self.num_epochs)) / 2
-
-    @property
-    def lr(self):
-        return self.lr_at(min(self.global_step // self.steps_per_epoch, self.num_epochs))
-
-    def step(self, rays_o, rays_d, rgb_gt):
-        """one training step on this rank's ray batch; returns (loss tensor, results dict)"""
-        model = self.model
-        if self.global_step % self.update_interval == 0:
-            model.update_density_grid(self.density_threshold * MAX_SAMPLES / 3 ** 0.5,
-                                      warmup=self.global_step < self.warmup_steps)
-        results = render(model, rays_o, rays_d, exp_step_factor=self.exp_step_factor,
-                         num_classes=self.num_classes, **self.render_kwargs)
-        if self.fused_loss:
-            # same value and gradients as sum(term.mean()) over NeRFLoss's default terms
-            loss, *_terms = FusedNeRFLoss.apply(results["rgb"], results["opacity"], results["ws"], results["deltas"],
-                                                results["ts"], results["rays_a"], rgb_gt, self.loss_fn.lambda_opa,
-                                                self.loss_fn.lambda_distortion)
-        else:
-            loss_d = self.loss_fn(results, {"rgb": rgb_gt})
-            loss = sum(lo.mean() for lo in loss_d.values())
-        loss.backward()
-        self.optimizer_step()
-        return loss.detach(), results
-
-    def optimizer_step(self):
-        world = self.buckets.world
-        self.global_step += 1
-        # lr of the epoch this step belongs to (the scheduler ticks at epoch boundaries)
-        lr = self.lr_at(min((self.global_step - 1) // self.steps_per_epoch, self.num_epochs))
-        if not self.sharded:
-            # clip + Adam stream 6.4 GB and touch no ray data: run them on a side stream so the next
-            # step's ray generation / AABB / marcher (latency bound, 128 waves) overlap; the field
-            # waits on `_params_ready` before it reads a parameter.
-            n = self.flat_grad.numel()
-            main = torch.cuda.current_stream()
-            side = self._opt_stream
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self.scalars.zero_()
-                call("sumsq", self.flat_grad, n, self.scalars[0:1])
-                call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2])
-                call("adam_step", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, n, float(lr), 0.9,
-                     0.999, 1e-8, 0.0, self.global_step, self.scalars[1:2], 1)
-                ev = torch.cuda.Event()
-                ev.record(side)
-            self.model._params_ready = ev
-            return
-        self.scalars.zero_()
-        # sharded: bucket 0's reduce-scatter was issued from the colour encoder's backward
-        nb = len(self.buckets.bounds) - 1
-        for i in range(1 if self.hooked0 else 0, nb):
-            self.buckets.reduce_scatter_bucket(i)
-        self.buckets.wait()
-        for (a, b) in self.shards:          # global grad norm = sqrt(sum over ranks of shard sums)
-            call("sumsq", self.flat_grad[a:b], b - a, self.scalars[0:1])
-        dist.all_reduce(self.scalars[0:1], op=dist.ReduceOp.SUM, group=self.group)
-        call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0 / world, self.scalars[1:2])
-        for i, (a, b) in enumerate(self.shards):
-            call("adam_step", self.flat_param[a:b], self.flat_grad[a:b], self.exp_avg[i], self.exp_avg_sq[i], b - a,
-                 float(lr), 0.9, 0.999, 1e-8, 0.0, self.global_step, self.scalars[1:2], 0)
-        for i in range(nb):
-            self.buckets.all_gather_bucket(i, self.flat_param)
-        self.flat_grad.zero_()              # the other ranks' slices hold partial sums: start clean
-        self.buckets.wait()
 
     def wait(self):
         """make the current stream wait for a pending side-stream optimizer step (call before reading
