@@ -27,6 +27,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix (MFMA) peak
 BYTES_PER_SAMPLE = {        # SURVEY.md §8(d), fp32, L=16, F=8 (per encoder, per sample)
     "grid_fwd": 4096 + 512,         # 8 corners x 16 levels x 32 B gathered + 512 B written
     "grid_bwd_param": 4096 + 512,   # 4096 B of atomic adds + 512 B of dL_dy read
@@ -50,6 +51,7 @@ def parse():
                     help="untimed training steps run during setup so that the occupancy grid and the field are in "
                          "the steady-state regime the reference spends >98 %% of its 20k steps in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-march-ahead", action="store_true", help="march every batch inside its own step")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--cpu-samples", type=int, default=64)
     return ap.parse_args()
@@ -138,12 +140,17 @@ def main():
 
     batches = [next_batch() for _ in range(min(args.warmup + args.steps, 64))]
 
-    def run(k, i0):
+    def run(k, i0, feed_next_run):
+        # the loader is one batch ahead (as the reference's DataLoader workers are): the trainer
+        # marches batch i+1 under step i's backward.  Exactly k batches are marched per call of
+        # run(): the warm-up's last step marches the timed region's first batch, the timed
+        # region's last step marches nothing.
         tot_samples = torch.zeros((), dtype=torch.int64, device=dev)
         last = None
         for i in range(k):
             o, d, gt = batches[(i0 + i) % len(batches)]
-            loss, res = trainer.step(o, d, gt)
+            nxt = batches[(i0 + i + 1) % len(batches)][:2] if (i + 1 < k or feed_next_run) else None
+            loss, res = trainer.step(o, d, gt, next_rays=None if args.no_march_ahead else nxt)
             tot_samples += res["total_samples"]
             last = (loss, res, gt)
         return tot_samples, last
@@ -151,14 +158,15 @@ def main():
     for _ in range(args.pretrain):  # setup: fresh rays every step, not part of warm-up or timing
         o, d, gt = next_batch()
         trainer.step(o, d, gt)
-    run(args.warmup, 0)
+    run(args.warmup, 0, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    _lib.PROFILE = {k: [] for k in ("grid_fwd", "grid_bwd_param", "grid_bwd_input", "adam_step")}
+    _lib.PROFILE = {k: [] for k in ("grid_fwd", "grid_bwd_param", "grid_bwd_input", "adam_step",
+                                    "linear_fwd", "linear_bwd_input", "linear_bwd_weight")}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tot_samples, last = run(args.steps, args.warmup)
+    tot_samples, last = run(args.steps, args.warmup, False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -188,6 +196,14 @@ def main():
                 gbs = [BYTES_PER_SAMPLE[name] * n / (m * 1e-3) / 1e9 for n, m in zip(ns, ms) if m > 0]
                 kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
                               "avg_samples": sum(ns) / len(ns), "GBps": sum(gbs) / max(len(gbs), 1)}
+            elif name.startswith("linear"):
+                # (.., n, n_in, n_out, ..) are int arguments 2,3,4 of all three entry points; only the
+                # MFMA-tiled launches count (the 1..16-wide heads run on the VALU "skinny" kernels)
+                sel = [(m, 2.0 * a[2] * a[3] * a[4]) for m, (_, _, a) in zip(ms, evs) if min(a[3], a[4]) >= 32 and m > 0]
+                if sel:
+                    t_ms, fl = sum(m for m, _ in sel), sum(f for _, f in sel)
+                    kern[name] = {"launches": len(sel), "total_ms": t_ms, "avg_ms": t_ms / len(sel),
+                                  "TFLOPs": fl / (t_ms * 1e-3) / 1e12}
             else:
                 kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms)}
         grid_names = [k for k in kern if k.startswith("grid")]
@@ -212,6 +228,16 @@ def main():
                     "frac; run merging + zero skipping + x-pair coalescing cut the real traffic to `traffic` bytes"
                     if dom == "grid_bwd_param" else "",
         }
+        # MFMA utilisation of the MLP products against the dense f32 MFMA peak of gfx950
+        lin = [kern[k] for k in kern if k.startswith("linear")]
+        mlp = None
+        if lin:
+            fl = sum(k["TFLOPs"] * k["total_ms"] for k in lin)
+            t_ms = sum(k["total_ms"] for k in lin)
+            mlp = {"bound": "mfma", "achieved": fl / t_ms, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": fl / t_ms / MFMA_F32_PEAK_TFLOPS, "ms_per_step": t_ms / args.steps,
+                   "note": "all MFMA-tiled linear_fwd / bwd_input / bwd_weight launches of the step, fp32 operands, "
+                           "v_mfma_f32_32x32x2_f32"}
         out = {
             "metric": "train rays/sec", "value": rays_total / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -229,6 +255,7 @@ def main():
                        "pretrain_steps": args.pretrain,
                        "parallelism": f"ray-batch dp{world}"},
             "roofline": roofline,
+            "mlp_mfma": mlp,
             "kernels": kern,
         }
         if world == 1 and not args.no_cpu_baseline:

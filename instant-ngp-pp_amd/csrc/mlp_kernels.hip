@@ -509,9 +509,8 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
     const int64_t n4 = n >> 2;
     float4* p4 = reinterpret_cast<float4*>(p); float4* g4 = reinterpret_cast<float4*>(g);
     float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
-        float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+    auto update = [&](float4& pp, const float4& gg, float4& mm, float4& vv) {
+        float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float gr = ga[j] * gs;
@@ -521,8 +520,27 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
             const float denom = sqrtf(va[j]) / bc2_sqrt + eps;
             pa[j] = pa[j] - step_size * (ma[j] / denom);
         }
+    };
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // two independent 16-B quads per lane and trip: the launch is capped well below full occupancy
+    // (other streams' kernels must be able to get wave slots), so the bytes in flight come from
+    // the unroll instead of from more waves
+    for (; i + stride < n4; i += 2 * stride) {
+        const int64_t k = i + stride;
+        float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
+        float4 pb = p4[k], gb = g4[k], mb = m4[k], vb = v4[k];
+        update(pa, ga, ma, va);
+        update(pb, gb, mb, vb);
+        p4[i] = pa; m4[i] = ma; v4[i] = va;
+        p4[k] = pb; m4[k] = mb; v4[k] = vb;
+        if (zero_grad) { g4[i] = zero4; g4[k] = zero4; }
+    }
+    for (; i < n4; i += stride) {
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        update(pp, gg, mm, vv);
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
-        if (zero_grad) g4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (zero_grad) g4[i] = zero4;
     }
     // tail
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -712,9 +730,14 @@ int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
+    static const int64_t cap = [] {
+        const char* e = getenv("NGP_ADAM_BLOCKS");
+        const long c = e ? atol(e) : 0;
+        return (int64_t)(c > 0 ? c : 512);  // 2 workgroups per CU: 5.2 TB/s alone (2048: 4.5) and leaves wave slots to other streams
+    }();
     int64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, step_size, beta1, beta2, eps, bc2_sqrt, weight_decay, grad_scale, zero_grad);
     return ngp_check_launch();

@@ -139,13 +139,20 @@ class _NegNormalize(Function):
         return dx, None
 
 
-def _wait_params(model):
-    """The trainer may run clip + Adam on a side stream (overlapping the next step's ray marching);
-    anything that reads parameters first waits for that update."""
+def _wait_params(model, rgb_table=True):
+    """The trainer runs clip + Adam on a side stream in two pieces — [density table | MLPs], then
+    the colour table (77 % of the bytes) — and anything that reads parameters first waits for the
+    piece it needs: the field starts on the density path while the colour table is still being
+    updated.  rgb_table=False waits for the first piece only."""
     ev = getattr(model, "_params_ready", None)
     if ev is not None:
         torch.cuda.current_stream().wait_event(ev)
         model._params_ready = None
+    if rgb_table:
+        ev = getattr(model, "_rgb_params_ready", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            model._rgb_params_ready = None
 
 
 class _FieldFn(Function):
@@ -164,7 +171,7 @@ class _FieldFn(Function):
     def forward(ctx, model, x, d, embed_a, xyz_table, W1, b1, W2, b2, rgb_table, rgb_p, nrm_p, sem_p):
         n = x.shape[0]
         dev = x.device
-        _wait_params(model)
+        _wait_params(model, rgb_table=False)
         xe, re = model.xyz_encoder, model.rgb_encoder
         C = model.semantic_header.n_output_dims
         E = 0 if embed_a is None else embed_a.shape[1]
@@ -193,6 +200,7 @@ class _FieldFn(Function):
         rgb_in = torch.empty(n, Kp, dtype=_f32, device=dev)
         dn = F.normalize(d, p=2, dim=-1, eps=1e-6)
         call("sh_fwd", ((dn + 1) / 2).contiguous(), n, 4, rgb_in, Kp)
+        _wait_params(model)   # the colour table's Adam piece ran under the density path above
         call("grid_fwd", re.desc, rgb_table, xn, n, rgb_in[:, 16:], Kp)
         if E:
             rgb_in[:, 144:K] = embed_a
@@ -403,7 +411,7 @@ class NGP(nn.Module):
     def density(self, x, return_feat=False, grad=True, grad_feat=True):
         """x (N,3) in [-scale, scale] -> sigmas (N) [, feat_rgb (N,128)]"""
         x = ((x - self.xyz_min) / (self.xyz_max - self.xyz_min)).contiguous()
-        _wait_params(self)
+        _wait_params(self, rgb_table=return_feat)
         if not (grad and torch.is_grad_enabled()):
             # inference (update_density_grid runs this on 1-2 M points): three launches, no graph
             with torch.no_grad():

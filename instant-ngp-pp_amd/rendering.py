@@ -22,9 +22,11 @@ NEAR_DISTANCE = 0.01
 def render(model, rays_o, rays_d, **kwargs):
     rays_o = rays_o.contiguous()
     rays_d = rays_d.contiguous()
-    _, hits_t, _ = RayAABBIntersector.apply(rays_o, rays_d, model.center, model.half_size, 1)
-    # 0 <= t1 < NEAR_DISTANCE -> NEAR_DISTANCE (rendering.py:30), one fused launch
-    call("clamp_near", hits_t, hits_t.shape[0], 1, NEAR_DISTANCE)
+    marched = kwargs.get('marched', None)
+    if marched is not None and not kwargs.get('test_time', False):
+        hits_t = marched.hits_t   # AABB + marcher already ran for exactly these rays (MarchAhead)
+    else:
+        hits_t = intersect_scene(model, rays_o, rays_d)
 
     fn = _render_rays_test if kwargs.get('test_time', False) else _render_rays_train
     results = fn(model, rays_o, rays_d, hits_t, **kwargs)
@@ -35,6 +37,67 @@ def render(model, rays_o, rays_d, **kwargs):
                 v = v.numpy()
             results[k] = v
     return results
+
+
+def intersect_scene(model, rays_o, rays_d):
+    """ray / scene-AABB intersection with the near clamp of rendering.py:25-30 -> hits_t (N_rays,1,2)"""
+    _, hits_t, _ = RayAABBIntersector.apply(rays_o, rays_d, model.center, model.half_size, 1)
+    # 0 <= t1 < NEAR_DISTANCE -> NEAR_DISTANCE, one fused launch
+    call("clamp_near", hits_t, hits_t.shape[0], 1, NEAR_DISTANCE)
+    return hits_t
+
+
+class MarchAhead:
+    """The ray-only front of a training step — AABB test, near clamp, occupancy marcher — for the
+    NEXT ray batch, on its own HIP stream.
+
+    None of it reads a network parameter, so it can run under the current step's backward /
+    optimizer.  The sample count comes back through a pinned host word and an event on that
+    stream: the host waits for the marcher alone, never for the main stream, and is therefore a
+    step ahead of the device when it enqueues the field kernels (the reference synchronises the
+    whole device at this point every step, custom_functions.py:93).  The result is handed to
+    render(..., marched=...) and is only valid for the same rays and the occupancy bitfield it
+    was marched with (the trainer does not march across a density-grid update)."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.pending = None
+
+    def launch(self, model, rays_o, rays_d, exp_step_factor=0.):
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)   # the rays and the bitfield were produced on the main stream
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            hits_t = intersect_scene(model, rays_o, rays_d)
+            noise = torch.rand_like(rays_o[:, 0])
+            out = vren.raymarching_train_untrimmed(rays_o, rays_d, hits_t[:, 0], model.density_bitfield,
+                                                   model.cascades, model.scale, exp_step_factor, noise,
+                                                   model.grid_size, MAX_SAMPLES)
+            self.count_host.copy_(out[5][:1], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self.pending = (rays_o, rays_d, exp_step_factor, hits_t, out, done)
+
+    def take(self, rays_o, rays_d, exp_step_factor=0.):
+        """-> the marched batch if it was launched for exactly these tensors, else None"""
+        p, self.pending = self.pending, None
+        if p is None or p[0] is not rays_o or p[1] is not rays_d or p[2] != exp_step_factor:
+            return None
+        _, _, _, hits_t, (rays_a, xyzs, dirs, deltas, ts, counter), done = p
+        done.synchronize()
+        n = int(self.count_host[0])
+        main = torch.cuda.current_stream()
+        main.wait_event(done)
+        for t in (hits_t, rays_a, xyzs, dirs, deltas, ts, counter):
+            t.record_stream(main)   # allocated on the side stream's pool, consumed on the main stream
+        m = _Marched()
+        m.hits_t, m.rays_a, m.total_samples = hits_t, rays_a, counter[0]
+        m.xyzs, m.dirs, m.deltas, m.ts = xyzs[:n], dirs[:n], deltas[:n], ts[:n]
+        return m
+
+
+class _Marched:
+    __slots__ = ("hits_t", "rays_a", "xyzs", "dirs", "deltas", "ts", "total_samples")
 
 
 def render_chunks(model, rays_o, rays_d, chunk_size, **kwargs):
@@ -145,10 +208,15 @@ def _render_rays_train(model, rays_o, rays_d, hits_t, **kwargs):
     T_threshold = kwargs.get('T_threshold', 1e-4)
     classes = kwargs.get('num_classes', 7)
     results = {}
-    with torch.no_grad():
-        rays_a, xyzs, dirs, results['deltas'], results['ts'], total_samples = RayMarcher.apply(
-            rays_o, rays_d, hits_t[:, 0], model.density_bitfield, model.cascades, model.scale, exp_step_factor,
-            model.grid_size, MAX_SAMPLES)
+    marched = kwargs.pop('marched', None)
+    if marched is not None:
+        rays_a, xyzs, dirs, total_samples = marched.rays_a, marched.xyzs, marched.dirs, marched.total_samples
+        results['deltas'], results['ts'] = marched.deltas, marched.ts
+    else:
+        with torch.no_grad():
+            rays_a, xyzs, dirs, results['deltas'], results['ts'], total_samples = RayMarcher.apply(
+                rays_o, rays_d, hits_t[:, 0], model.density_bitfield, model.cascades, model.scale, exp_step_factor,
+                model.grid_size, MAX_SAMPLES)
     results['rays_a'] = rays_a
     results['total_samples'] = total_samples
 

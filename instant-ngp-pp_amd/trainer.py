@@ -25,7 +25,7 @@ import torch.distributed as dist
 
 from ._lib import call
 from .losses import FusedNeRFLoss, NeRFLoss
-from .rendering import MAX_SAMPLES, render
+from .rendering import MAX_SAMPLES, MarchAhead, render
 
 _f32 = torch.float32
 
@@ -128,6 +128,7 @@ class NGPTrainer:
         self.group = group
         self._flatten()
         self._opt_stream = torch.cuda.Stream(device=self.flat_param.device) if self.flat_param.is_cuda else None
+        self._march_ahead = MarchAhead(self.flat_param.device) if self.flat_param.is_cuda else None
 
     # ------------------------------------------------------------------ flat parameter store
     def _flatten(self):
@@ -191,14 +192,30 @@ class NGPTrainer:
     def lr(self):
         return self.lr_at(min(self.global_step // self.steps_per_epoch, self.num_epochs))
 
-    def step(self, rays_o, rays_d, rgb_gt):
-        """one training step on this rank's ray batch; returns (loss tensor, results dict)"""
+    def step(self, rays_o, rays_d, rgb_gt, next_rays=None):
+        """one training step on this rank's ray batch; returns (loss tensor, results dict).
+
+        next_rays = (rays_o, rays_d) of the FOLLOWING step, if the caller already has them (a
+        data loader that is one batch ahead): their AABB test and occupancy march are then run on a
+        side stream under this step's backward and the next call picks the result up, provided it
+        is called with the very same tensors and no density-grid update lies in between."""
         model = self.model
         if self.global_step % self.update_interval == 0:
             model.update_density_grid(self.density_threshold * MAX_SAMPLES / 3 ** 0.5,
                                       warmup=self.global_step < self.warmup_steps)
+        ahead = self._march_ahead
+        marched = None
+        if ahead is not None and next_rays is not None:
+            marched = ahead.take(rays_o, rays_d, self.exp_step_factor)
+            if marched is None:   # nothing in flight for this batch: march it now, same route
+                ahead.launch(model, rays_o, rays_d, self.exp_step_factor)
+                marched = ahead.take(rays_o, rays_d, self.exp_step_factor)
+            if (self.global_step + 1) % self.update_interval != 0:
+                ahead.launch(model, next_rays[0], next_rays[1], self.exp_step_factor)
+        elif ahead is not None:
+            marched = ahead.take(rays_o, rays_d, self.exp_step_factor)
         results = render(model, rays_o, rays_d, exp_step_factor=self.exp_step_factor,
-                         num_classes=self.num_classes, **self.render_kwargs)
+                         num_classes=self.num_classes, marched=marched, **self.render_kwargs)
         if self.fused_loss:
             # same value and gradients as sum(term.mean()) over NeRFLoss's default terms
             loss, *_terms = FusedNeRFLoss.apply(results["rgb"], results["opacity"], results["ws"], results["deltas"],
@@ -228,11 +245,19 @@ class NGPTrainer:
                 self.scalars.zero_()
                 call("sumsq", self.flat_grad, n, self.scalars[0:1])
                 call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2])
-                call("adam_step", self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, n, float(lr), 0.9,
-                     0.999, 1e-8, 0.0, self.global_step, self.scalars[1:2], 1)
-                ev = torch.cuda.Event()
-                ev.record(side)
-            self.model._params_ready = ev
+                # two pieces: [density table | MLPs] first — the next forward starts on them — then
+                # the colour table, which the field does not read before its colour branch
+                b0 = self.buckets.bounds[1] if len(self.buckets.bounds) > 2 else 0
+                events = []
+                for lo, hi in ((b0, n), (0, b0)):
+                    if hi > lo:
+                        call("adam_step", self.flat_param[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi],
+                             self.exp_avg_sq[lo:hi], hi - lo, float(lr), 0.9, 0.999, 1e-8, 0.0, self.global_step,
+                             self.scalars[1:2], 1)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    events.append(ev)
+            self.model._params_ready, self.model._rgb_params_ready = events
             return
         self.scalars.zero_()
         # sharded: bucket 0's reduce-scatter was issued from the colour encoder's backward
@@ -256,9 +281,10 @@ class NGPTrainer:
     def wait(self):
         """make the current stream wait for a pending side-stream optimizer step (call before reading
         parameters / gradients outside the model's own forward)"""
-        ev = getattr(self.model, "_params_ready", None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+        for name in ("_params_ready", "_rgb_params_ready"):
+            ev = getattr(self.model, name, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
 
     # ------------------------------------------------------------------ multi-GPU helpers
     def broadcast_state(self, src=0):

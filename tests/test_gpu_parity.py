@@ -604,6 +604,45 @@ def test_trainer_steps_reduce_loss(ngp):
     assert model.rgb_encoder.params.data_ptr() == tr.flat_param.data_ptr()
 
 
+def test_trainer_march_ahead_matches_inline(ngp):
+    """Marching batch k+1 on the side stream under step k (MarchAhead) gives the same training run
+    as marching every batch inside its own step: identical sample counts (the marcher is
+    deterministic and sees the same bitfield and noise), losses equal up to atomic summation order.
+    Crosses two density-grid updates (steps 0 and 16), where nothing is marched ahead."""
+    from ngp_amd.synthetic import LegoProxy
+    from ngp_amd.trainer import NGPTrainer
+    scene = LegoProxy(n_images=20, img_wh=(200, 200), device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    batches = []
+    for i in range(20):
+        img, pix = scene.sample_batch(1024, generator=gen)
+        o, d = scene.rays(img, pix)
+        gt, _ = scene.ground_truth(o, d, n_quad=64)
+        batches.append((o, d, gt))
+    runs = []
+    for ahead in (False, True):
+        torch.manual_seed(5)
+        model = ngp.networks.NGP(scale=0.5).to(DEV)
+        G = model.grid_size
+        model.register_buffer("density_grid", torch.zeros(model.cascades, G ** 3, device=DEV))
+        coords = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=DEV)] * 3, indexing="ij"), -1)
+        model.register_buffer("grid_coords", coords.reshape(-1, 3).contiguous())
+        tr = NGPTrainer(model, lr=1e-2)
+        torch.manual_seed(6)
+        losses, counts = [], []
+        for i, (o, d, gt) in enumerate(batches):
+            nxt = batches[i + 1][:2] if (ahead and i + 1 < len(batches)) else None
+            loss, res = tr.step(o, d, gt, next_rays=nxt)
+            losses.append(float(loss))
+            counts.append(int(res["total_samples"]))
+        tr.wait()
+        runs.append((losses, counts))
+    (l0, c0), (l1, c1) = runs
+    assert c0[:16] == c1[:16]           # until the first re-thresholded grid update the bitfields agree exactly
+    close(np.array(l1), np.array(l0), 2e-2, 1e-6)
+    assert abs(c0[-1] - c1[-1]) <= 0.02 * c0[-1]
+
+
 def test_differentiable_normals_h4(ngp):
     """--normal_ref path: a loss on normals_raw reaches the density table through the grid's double
     backward; checked against a central difference along a random direction in parameter space."""

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Per-step timeline from a rocprofv3 `*_kernel_trace.csv`: picks one training step near the end of
+the run (steps are delimited by sumsq_kernel launches) and prints every kernel with its start offset,
+duration, queue and the idle gap on the device before it.  Also prints the busy/idle split of the step.
+
+usage: timeline.py <kernel_trace.csv> [steps_from_end=3]
+"""
+import csv
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z0-9_:]+(?:<[^()]*?>)?)", name)
+    s = m.group(1) if m else name
+    if s.startswith("at::native"):
+        inner = re.search(r"(CUDAFunctor\w*|FillFunctor|\w+Functor|\w+_kernel_cuda|NormTwoOps|MeanOps|sum_functor|"
+                          r"CatArray\w+|scan\w+|reduce_kernel|index\w+)", name)
+        s = "torch:" + (inner.group(1) if inner else s.split("::")[-1])
+    return s[:58]
+
+
+def main(path, back=3):
+    rows = []
+    for r in csv.DictReader(open(path)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
+    rows.sort()
+    adam = [i for i, r in enumerate(rows) if "sumsq_kernel" in r[2]]
+    if len(adam) < back + 2:
+        raise SystemExit("not enough steps in the trace")
+    lo, hi = adam[-back - 1], adam[-back]          # [adam of step k-1 ... adam of step k)
+    step = rows[lo:hi]
+    t0 = step[0][0]
+    wall = rows[hi][0] - t0
+    print(f"# step of {len(step)} launches, wall (sumsq start -> next sumsq start) {wall/1e3:.1f} us")
+    print(f"{'start_us':>9s} {'dur_us':>8s} {'gap_us':>7s} {'q':>3s}  kernel")
+    busy_end = t0
+    idle = 0
+    for s, e, n, q in step:
+        gap = max(0, s - busy_end)
+        idle += gap
+        print(f"{(s-t0)/1e3:9.1f} {(e-s)/1e3:8.1f} {gap/1e3:7.1f} {q:>3s}  {short(n)}")
+        busy_end = max(busy_end, e)
+    print(f"# device idle inside the step: {idle/1e3:.1f} us of {wall/1e3:.1f} us")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3)
