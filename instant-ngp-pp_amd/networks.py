@@ -144,14 +144,17 @@ def _wait_params(model, rgb_table=True):
     the colour table (77 % of the bytes) — and anything that reads parameters first waits for the
     piece it needs: the field starts on the density path while the colour table is still being
     updated.  rgb_table=False waits for the first piece only."""
+    # either a HIP event (single GPU: Adam on the optimizer stream) or the handle of an async
+    # all-gather of the updated parameter shards (sharded optimizer): both make the current stream
+    # wait through .wait()
     ev = getattr(model, "_params_ready", None)
     if ev is not None:
-        torch.cuda.current_stream().wait_event(ev)
+        ev.wait()
         model._params_ready = None
     if rgb_table:
         ev = getattr(model, "_rgb_params_ready", None)
         if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+            ev.wait()
             model._rgb_params_ready = None
 
 

@@ -84,17 +84,21 @@ class GradBuckets:
             w.wait()
             out.copy_(self.flat[a:b])
 
-    def all_gather_bucket(self, i, flat_param, shard):
+    def all_gather_bucket(self, i, flat_param, shard, detach=False):
         """flat_param[bucket i] <- concatenation over ranks of `shard` (own buffer)"""
         if self.world == 1:
-            return
+            return None
         lo, hi = self.bounds[i], self.bounds[i + 1]
         if self._native_rs():
-            self.works.append(dist.all_gather_into_tensor(flat_param[lo:hi], shard, group=self.group, async_op=True))
+            w = dist.all_gather_into_tensor(flat_param[lo:hi], shard, group=self.group, async_op=True)
         else:
             s = (hi - lo) // self.world
             views = [flat_param[lo + r * s: lo + (r + 1) * s] for r in range(self.world)]
-            self.works.append(dist.all_gather(views, shard, group=self.group, async_op=True))
+            w = dist.all_gather(views, shard, group=self.group, async_op=True)
+        if detach:
+            return w   # the caller waits for it where the gathered parameters are first read
+        self.works.append(w)
+        return None
 
     def wait(self):
         for w in self.works:
@@ -273,9 +277,15 @@ class NGPTrainer:
         for i in range(nb):
             call("adam_step", self.param_shard[i], self.grad_shard[i], self.exp_avg[i], self.exp_avg_sq[i],
                  self.grad_shard[i].numel(), float(lr), 0.9, 0.999, 1e-8, 0.0, self.global_step, self.scalars[1:2], 0)
-        for i in range(nb):
-            self.buckets.all_gather_bucket(i, self.flat_param, self.param_shard[i])
-        self.buckets.wait()
+        # publish the updated slices: [density table | MLPs] first, the colour table (77 % of the
+        # bytes) second; the field waits for each gather where it first reads those parameters, so
+        # the large one runs under the next step's marcher and density path
+        order = list(range(nb - 1, -1, -1))
+        works = {i: self.buckets.all_gather_bucket(i, self.flat_param, self.param_shard[i], detach=True) for i in order}
+        if nb == 2:
+            self.model._params_ready, self.model._rgb_params_ready = works[1], works[0]
+        else:
+            self.model._params_ready = works[0]
 
 
     def wait(self):
@@ -284,7 +294,7 @@ class NGPTrainer:
         for name in ("_params_ready", "_rgb_params_ready"):
             ev = getattr(self.model, name, None)
             if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
+                ev.wait()
 
     # ------------------------------------------------------------------ multi-GPU helpers
     def broadcast_state(self, src=0):

@@ -170,6 +170,15 @@ def _bucket_worker(rank, world, port, q):
         b.all_gather_bucket(i, params, shards[i] * 0.5)
     b.wait()
     ok = ok and torch.allclose(params, total * 0.5, atol=1e-6)
+    # detached gathers (the trainer hands these to the model, which waits where it first reads
+    # the parameters): small bucket first, then the large one
+    params2 = torch.zeros(1000)
+    w1 = b.all_gather_bucket(1, params2, shards[1] * 0.25, detach=True)
+    w0 = b.all_gather_bucket(0, params2, shards[0] * 0.25, detach=True)
+    ok = ok and not b.works
+    w1.wait()
+    w0.wait()
+    ok = ok and torch.allclose(params2, total * 0.25, atol=1e-6)
     # plain all-reduce mode
     flat2 = mine.clone()
     b2 = GradBuckets(flat2, [0, 600, 1000])
