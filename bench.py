@@ -70,7 +70,25 @@ def cpu_baseline(model, scene, n_rays, n_samples):
     img, pix = scene.sample_batch(n_rays, generator=g)
     o, d = scene.rays(img, pix)
     o, d = o.cpu().numpy(), d.cpu().numpy()
-    nocuda.render([field, field], o, d, [n_samples])  # warm-up (page-in, OpenMP pool)
+    ref = nocuda.render([field, field], o, d, [n_samples])  # warm-up (page-in, OpenMP pool)
+    # matched-PSNR check of the north star: the same rays AND sample depths through the HIP field +
+    # compositor (render_dense) vs this CPU path, both scored against the scene's ground truth
+    from ngp_amd.rendering import render_dense
+    dev = scene.device
+    o_t, d_t = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    gpu = render_dense(model, o_t, d_t, torch.from_numpy(ref["z_vals0"]).to(dev))
+    gt, _ = scene.ground_truth(o_t, d_t, n_quad=512)
+    gt = gt.cpu().numpy()
+
+    def _psnr(a, b):
+        return float(-10 * np.log10(np.mean((a - b) ** 2)))
+    rgb_gpu = gpu["rgb"].cpu().numpy()
+    hit = np.isfinite(ref["rgb0"]).all(-1)   # rays that miss the scene box have near == far -> 0/0 in
+    ref["rgb0"], rgb_gpu, gt = ref["rgb0"][hit], rgb_gpu[hit], gt[hit]   # rendering_noCUDA.py:146 (both paths)
+    match = {"psnr_cpu_path": _psnr(ref["rgb0"], gt), "psnr_hip_same_samples": _psnr(rgb_gpu, gt),
+             "psnr_hip_vs_cpu_path": _psnr(rgb_gpu, ref["rgb0"])}
+    match["psnr_delta"] = match["psnr_hip_same_samples"] - match["psnr_cpu_path"]
+    match["rays_compared"] = int(hit.sum())
     reps, t0 = 0, time.perf_counter()
     while True:
         nocuda.render([field, field], o, d, [n_samples])
@@ -83,6 +101,7 @@ def cpu_baseline(model, scene, n_rays, n_samples):
         "samples_per_s": n_rays * n_samples * reps / el,
         "sample": f"{reps}x forward render of {n_rays} rays x {n_samples} dense samples "
                   f"(oracle restatement of rendering_noCUDA.render + CPU hash-grid/MLP field, {el:.1f}s)",
+        "parity": match,
     }
 
 

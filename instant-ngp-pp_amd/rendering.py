@@ -114,6 +114,36 @@ def render_chunks(model, rays_o, rays_d, chunk_size, **kwargs):
     return results
 
 
+@torch.no_grad()
+def render_dense(model, rays_o, rays_d, z_vals, **kwargs):
+    """The dense-sample path of rendering_noCUDA.py:103-214 on the HIP kernels: the field at the
+    caller's depths `z_vals` (N_rays, S), composited as raw2outputs does (custom_functions.py:280-321:
+    dists = diff(z)·|d| with a last interval of 1e10, no early termination).  Used to compare this
+    library with the reference's noCUDA path on identical rays AND identical samples.
+    -> opacity, depth, rgb, normal_raw, normal_pred, semantic (logit sums), ws (N_rays, S)"""
+    classes = kwargs.get('num_classes', 7)
+    rays_o, rays_d, z_vals = rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous()
+    n_rays, S = z_vals.shape
+    dev = rays_o.device
+    xyzs = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]).reshape(-1, 3).contiguous()
+    dirs = rays_d[:, None, :].expand(-1, S, -1).reshape(-1, 3).contiguous()
+    sigmas, rgbs, normals_raw, normals_pred, sems = model(xyzs, dirs, **kwargs)
+    dists = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], torch.full_like(z_vals[:, :1], 1e10)], -1)
+    dists = (dists * torch.norm(rays_d, dim=-1, keepdim=True)).reshape(-1).contiguous()
+    idx = torch.arange(n_rays, device=dev, dtype=torch.int64)
+    rays_a = torch.stack([idx, idx * S, torch.full_like(idx, S)], -1).contiguous()
+    out = {}
+    ts = z_vals.reshape(-1).contiguous()
+    _, out['opacity'], out['depth'], out['rgb'], out['normal_pred'], out['semantic'], ws = vren.composite_train_fw(
+        sigmas.contiguous(), rgbs.contiguous(), normals_pred.contiguous(), sems.contiguous(), dists, ts, rays_a,
+        0.0, classes)
+    out['normal_raw'] = vren.composite_train_fw(
+        sigmas.contiguous(), rgbs.contiguous(), normals_raw.contiguous(), sems.contiguous(), dists, ts, rays_a,
+        0.0, classes)[4]
+    out['ws'] = ws.view(n_rays, S)
+    return out
+
+
 def volume_render(model, rays_o, rays_d, hits_t, opacity, depth, rgb, normal_pred, normal_raw, sem, **kwargs):
     """Progressive test-time marching (rendering.py:46-133): the per-ray accumulators are updated
     in place; returns the total number of samples evaluated."""
