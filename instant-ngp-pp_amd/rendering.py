@@ -254,7 +254,7 @@ def _render_rays_train(model, rays_o, rays_d, hits_t, **kwargs):
     # reference this rewrites kwargs in place (rendering.py:217-219)
     for k, v in kwargs.items():
         if isinstance(v, torch.Tensor):
-            kwargs[k] = torch.repeat_interleave(v[rays_a[:, 0]], rays_a[:, 2], 0)
+            kwargs[k] = torch.repeat_interleave(v[rays_a[:, 0]], rays_a[:, 2], 0, output_size=xyzs.shape[0])
     sigmas, rgbs, normals_raw, normals_pred, sems = model(xyzs, dirs, **kwargs)
     results['sigma'] = sigmas
     results['xyzs'] = xyzs

@@ -79,6 +79,10 @@ class CpuNGP:
         dn = _normalize(np.asarray(d, F32))
         sh = oracle.sh_fwd((dn + 1) / 2, 4)
         inp = np.concatenate([sh, feat_rgb] + ([np.asarray(embed_a, F32)] if embed_a is not None and self.Wr1.shape[1] > 144 else []), 1)
+        if inp.shape[1] < self.Wr1.shape[1]:
+            # tcnn pads the network input to a multiple of 16 with ones:
+            # 16 + 128 + 8 appearance dims = 152 -> 160
+            inp = np.concatenate([inp, np.ones((inp.shape[0], self.Wr1.shape[1] - inp.shape[1]), F32)], 1)
         hr = oracle.linear_fwd(inp, self.Wr1, None, "ReLU")
         rgbs = oracle.linear_fwd(hr, self.Wr2, None, "Sigmoid")[:, :3]
         return sigma, rgbs, normals_raw, normals_pred, sems, None

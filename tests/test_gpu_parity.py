@@ -473,9 +473,9 @@ def test_adam_matches_torch(ngp):
 
 
 # ---------------------------------------------------------------------------- NGP field (fused node)
-def _make_model(ngp, embed_a=False, table_scale=0.3):
+def _make_model(ngp, embed_a=False, table_scale=0.3, scale=0.5):
     torch.manual_seed(5)
-    model = ngp.networks.NGP(scale=0.5, embed_a=embed_a, embed_a_len=8).to(DEV)
+    model = ngp.networks.NGP(scale=scale, embed_a=embed_a, embed_a_len=8).to(DEV)
     with torch.no_grad():  # tcnn's 1e-4 init makes every feature ~0: use O(1) tables for a real test
         model.xyz_encoder.params.uniform_(-table_scale, table_scale)
         model.rgb_encoder.params.uniform_(-table_scale, table_scale)
@@ -507,6 +507,72 @@ def test_field_forward_matches_oracle(ngp):
     # test path returns the same values with the two normals swapped
     assert torch.equal(sig, sig_t) and torch.equal(rgb, rgb_t)
     assert torch.equal(n_pred, n_pred_t) and torch.equal(n_raw, n_raw_t) and torch.equal(sem, sem_t)
+
+
+@pytest.mark.parametrize("scale", [8.0, 16.0])
+def test_field_forward_matches_oracle_unbounded(ngp, scale):
+    """BASELINE configs 2/3 (Playground-like scale 8 with appearance codes, bicycle-like scale 16):
+    per-level growth b = exp(ln(2048*scale/16)/15), positions normalised by the larger box."""
+    from oracle.field import CpuNGP
+    model = _make_model(ngp, embed_a=True, scale=scale)
+    g = rng(201)
+    n = 1200
+    x = ((g.random((n, 3)) - 0.5) * 2 * scale * 0.98).astype(np.float32)
+    x[: n // 2] *= 0.05          # half of the points near the origin, where the scene is
+    d = g.normal(size=(n, 3)).astype(np.float32)
+    emb = g.normal(size=(n, 8)).astype(np.float32)
+    with torch.no_grad():
+        sig, rgb, n_raw, n_pred, sem = model(T(x), T(d), embedding_a=T(emb))
+    state = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    ref = CpuNGP(state, scale=scale)
+    rs, rrgb, rn_raw, rn_pred, rsem, _ = ref(x, d, emb)
+    close(N(sig), rs, 2e-4, 1e-5)
+    close(N(rgb), rrgb, 2e-4, 1e-5)
+    close(N(n_pred), rn_pred, 1e-3, 1e-4)
+    close(N(sem), rsem, 2e-4, 1e-5)
+    cos = (N(n_raw) * rn_raw).sum(-1)
+    assert np.percentile(cos, 2) > 0.999
+
+
+@pytest.mark.parametrize("cfg", [
+    # scale, embed_a, exp_step_factor, rays, random_bg       (BASELINE configs 2 and 3, shapes only)
+    (8.0, True, 1 / 256, 8192, True),
+    (16.0, False, 1 / 256, 16384, False),
+])
+def test_trainer_unbounded_configs(ngp, cfg):
+    """Playground-like (K=5 cascades, exponential stepping, appearance codes, random background) and
+    bicycle-like (K=6, 16384 rays) configurations run the full schedule: finite, and the loss drops."""
+    from ngp_amd.synthetic import LegoProxy
+    from ngp_amd.trainer import NGPTrainer
+    scale, embed_a, esf, n_rays, random_bg = cfg
+    torch.manual_seed(31)
+    model = ngp.networks.NGP(scale=scale, embed_a=embed_a, embed_a_len=8).to(DEV)
+    assert model.cascades == (5 if scale == 8.0 else 6)
+    G = model.grid_size
+    model.register_buffer("density_grid", torch.zeros(model.cascades, G ** 3, device=DEV))
+    coords = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=DEV)] * 3, indexing="ij"), -1)
+    model.register_buffer("grid_coords", coords.reshape(-1, 3).contiguous())
+    scene = LegoProxy(n_images=20, img_wh=(200, 200), device=DEV)
+    codes = torch.nn.Parameter(torch.zeros(20, 8, device=DEV)) if embed_a else None
+    tr = NGPTrainer(model, lr=1e-2, exp_step_factor=esf)
+    gen = torch.Generator(device=DEV).manual_seed(32)
+    losses = []
+    for i in range(24):
+        img, pix = scene.sample_batch(n_rays, generator=gen)
+        o, d = scene.rays(img, pix)
+        gt, _ = scene.ground_truth(o, d, n_quad=64)
+        tr.render_kwargs = {"random_bg": random_bg}
+        if embed_a:
+            tr.render_kwargs["embedding_a"] = codes[img]
+        loss, res = tr.step(o, d, gt)
+        losses.append(float(loss))
+        assert res["rgb"].shape == (n_rays, 3) and int(res["total_samples"]) == res["xyzs"].shape[0]
+    tr.wait()
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-4:]) < np.mean(losses[:4])
+    assert torch.isfinite(tr.flat_param).all()
+    if embed_a:
+        assert codes.grad is not None and torch.isfinite(codes.grad).all() and codes.grad.abs().sum() > 0
 
 
 @pytest.mark.parametrize("embed_a", [False, True])
