@@ -149,7 +149,9 @@ int ngp_composite_test_fw(const float* sigmas, const float* rgbs, const float* n
  * past the stop), so callers need not pre-zero per-sample outputs; per-ray
  * outputs are written for every rays_a row.  In ngp_composite_train_bw the outputs
  * dL_dnormals_pred / dL_dsems may be NULL (together with their upstream gradients)
- * when the loss does not use the composited normal / semantic maps.
+ * when the loss does not use the composited normal / semantic maps, and any of
+ * the upstream gradients dL_dopacity / dL_ddepth / dL_drgb / dL_dws may be NULL,
+ * which reads as all zeros.
  * ---------------------------------------------------------------------- */
 int ngp_composite_alpha_fw(const float* sigmas, const float* deltas, const int64_t* rays_a,
                            float T_threshold, int n_rays, float* alphas, float* ws, void* stream);
@@ -202,17 +204,19 @@ int ngp_distortion_loss_bw(const float* dL_dloss, const float* ws_inclusive_scan
 
 /* ------------------------------------------------------------------------
  * L1  loss glue, fused (each replaces a chain of torch elementwise ops in the reference)
- * ngp_nerf_loss      : NeRFLoss rgb + opacity terms (losses.py:96-100): sums[0] += sum (rgb-gt)^2,
- *                      sums[1] += sum -o log o (o = opacity+1e-10), and their gradients for the
- *                      mean-reduced loss: d_rgb = 2(rgb-gt)/(3n), d_opacity = lambda(-log o - 1)/n.
+ * ngp_nerf_loss      : NeRFLoss default terms reduced as train.py:307 does (sum of term means),
+ *                      losses.py:96-105: terms[1] += mean (rgb-gt)^2, terms[2] += lambda_o mean(-o log o)
+ *                      (o = opacity+1e-10), terms[3] += lambda_d mean(distortion) (per-ray distortion
+ *                      loss of ngp_distortion_loss_fw, may be NULL), terms[0] += their sum; and the
+ *                      gradients d_rgb = 2(rgb-gt)/(3n), d_opacity = lambda_o(-log o - 1)/n.
  * ngp_refloss_inputs : normals_diff = (n_raw-n_pred)^2, normals_ori = max(<n_raw, normalize(dir)>,0)^2
  *                      (rendering.py:243-245).
  * ngp_neg_normalize  : y = -F.normalize(x*scale3, eps=1e-6) on rows of 3 (networks.py:210,215), and
  *                      its backward.
  * ---------------------------------------------------------------------- */
-int ngp_nerf_loss(const float* rgb, const float* target_rgb, const float* opacity, int n_rays,
-                  float lambda_opacity, float* sums /* (2), caller zeroes */, float* d_rgb,
-                  float* d_opacity, void* stream);
+int ngp_nerf_loss(const float* rgb, const float* target_rgb, const float* opacity,
+                  const float* distortion, int n_rays, float lambda_opacity, float lambda_distortion,
+                  float* terms /* (4), caller zeroes */, float* d_rgb, float* d_opacity, void* stream);
 int ngp_refloss_inputs(const float* normals_raw, const float* normals_pred, const float* dirs, int64_t n,
                        float* normals_diff, float* normals_ori, void* stream);
 int ngp_neg_normalize(const float* x, int64_t ldx, const float* scale3 /* device (3) or NULL */, int64_t n,
@@ -271,6 +275,10 @@ int ngp_grid_bwd_bwd_input(const ngp_grid_desc* desc, const float* table, const 
  * networks.py:78-85,128-135).  x (n,3) in [0,1] -> y (n, degree^2).
  * ---------------------------------------------------------------------- */
 int ngp_sh_fwd(const float* x, int64_t n, int degree, float* y, int64_t ldy, void* stream);
+
+/* same basis of a raw view direction d (n,3): y = SH((normalize(d, eps=1e-6) + 1) / 2), the three
+ * steps of networks.py:198,222 (F.normalize, remap to [0,1], dir_encoder) in one launch */
+int ngp_sh_fwd_dirs(const float* d, int64_t n, int degree, float* y, int64_t ldy, void* stream);
 int ngp_sh_bwd_input(const float* x, const float* dL_dy, int64_t n, int degree,
                      float* dL_dx, void* stream);
 

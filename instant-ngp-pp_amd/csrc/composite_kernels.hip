@@ -157,8 +157,10 @@ __global__ void composite_train_bw_kernel(const float* __restrict__ dL_dopacity,
     const size_t r = (size_t)sg.ray;
     const float R = rgb[3 * r], G = rgb[3 * r + 1], B = rgb[3 * r + 2];
     const float O = opacity[r], D = depth[r];
-    const float gR = dL_drgb[3 * r], gG = dL_drgb[3 * r + 1], gB = dL_drgb[3 * r + 2];
-    const float gO = dL_dopacity[r], gD = dL_ddepth[r];
+    // a NULL upstream gradient is an all-zero one (outputs the loss never touched)
+    float gR = 0.0f, gG = 0.0f, gB = 0.0f;
+    if (dL_drgb) { gR = dL_drgb[3 * r]; gG = dL_drgb[3 * r + 1]; gB = dL_drgb[3 * r + 2]; }
+    const float gO = dL_dopacity ? dL_dopacity[r] : 0.0f, gD = dL_ddepth ? dL_ddepth[r] : 0.0f;
     float gNx = 0.0f, gNy = 0.0f, gNz = 0.0f;
     if (dL_dnormals) { gNx = dL_dnormal[3 * r]; gNy = dL_dnormal[3 * r + 1]; gNz = dL_dnormal[3 * r + 2]; }
     float gS[CMAX > 0 ? CMAX : 1];
@@ -167,8 +169,10 @@ __global__ void composite_train_bw_kernel(const float* __restrict__ dL_dopacity,
 
     // total of dL_dws*ws over the whole segment (volumerendering.cu:206-210)
     float tot = 0.0f;
-    for (int k = lane; k < sg.n; k += 32) tot += dL_dws[sg.start + k] * ws[sg.start + k];
-    tot = half_sum(tot);
+    if (dL_dws) {
+        for (int k = lane; k < sg.n; k += 32) tot += dL_dws[sg.start + k] * ws[sg.start + k];
+        tot = half_sum(tot);
+    }
 
     float T_run = 1.0f, r_run = 0, g_run = 0, b_run = 0, d_run = 0, p_run = 0;
     int k0 = 0;
@@ -180,7 +184,7 @@ __global__ void composite_train_bw_kernel(const float* __restrict__ dL_dopacity,
         float cr = 0, cg = 0, cb = 0, tt = 0, dws = 0, dl = 0, wsv = 0;
         if (c.valid) {
             cr = rgbs[3 * s]; cg = rgbs[3 * s + 1]; cb = rgbs[3 * s + 2];
-            tt = ts[s]; dws = dL_dws[s]; dl = deltas[s]; wsv = ws[s];
+            tt = ts[s]; dws = dL_dws ? dL_dws[s] : 0.0f; dl = deltas[s]; wsv = ws[s];
         }
         const float ri = r_run + half_incl_scan_add(w * cr, lane);
         const float gi = g_run + half_incl_scan_add(w * cg, lane);
@@ -441,17 +445,21 @@ __global__ void segment_csr_kernel(const float* __restrict__ src, const int64_t*
 }
 
 // ------------------------------------------------------------------ fused loss / glue kernels
-// NeRFLoss rgb + opacity terms (losses.py:96-100) with their gradients in one pass:
-//   sums[0] += sum (rgb-gt)^2          d_rgb     = g_rgb * 2 (rgb-gt)            g_rgb = 1/(3 n)
-//   sums[1] += sum -o log o, o=op+1e-10 d_opacity = g_op * (-log o - 1)          g_op = lambda/n
+// NeRFLoss default terms (losses.py:96-105, reduced as train.py:307 does: sum of term means) with the
+// gradients of the rgb / opacity terms, one pass over the rays:
+//   terms[1] += mean (rgb-gt)^2                    d_rgb     = 2 (rgb-gt) / (3 n)
+//   terms[2] += lambda_o mean(-o log o), o=op+1e-10 d_opacity = lambda_o (-log o - 1) / n
+//   terms[3] += lambda_d mean(dist)                (dist = per-ray distortion loss, may be NULL)
+//   terms[0] += their sum
 __global__ void __launch_bounds__(256) nerf_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ gt,
-                                                        const float* __restrict__ opacity, int n_rays, float g_rgb,
-                                                        float g_op, float* __restrict__ sums,
+                                                        const float* __restrict__ opacity,
+                                                        const float* __restrict__ dist, int n_rays, float g_rgb,
+                                                        float g_op, float g_dist, float* __restrict__ terms,
                                                         float* __restrict__ d_rgb, float* __restrict__ d_opacity)
 {
-    __shared__ float part[2][4];
+    __shared__ float part[3][4];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    float s0 = 0.0f, s1 = 0.0f;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
     if (r < n_rays) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -463,14 +471,24 @@ __global__ void __launch_bounds__(256) nerf_loss_kernel(const float* __restrict_
         const float lg = logf(o);
         s1 = -o * lg;
         d_opacity[r] = g_op * (-lg - 1.0f);
+        if (dist) s2 = dist[r];
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
-    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s0; part[1][threadIdx.x >> 6] = s1; }
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = s0; part[1][threadIdx.x >> 6] = s1; part[2][threadIdx.x >> 6] = s2;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(sums, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
-        atomicAdd(sums + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+        const float t_rgb = (part[0][0] + part[0][1] + part[0][2] + part[0][3]) * g_rgb;
+        const float t_op = (part[1][0] + part[1][1] + part[1][2] + part[1][3]) * g_op;
+        const float t_dist = (part[2][0] + part[2][1] + part[2][2] + part[2][3]) * g_dist;
+        atomicAdd(terms, t_rgb + t_op + t_dist);
+        atomicAdd(terms + 1, t_rgb);
+        atomicAdd(terms + 2, t_op);
+        atomicAdd(terms + 3, t_dist);
     }
 }
 
@@ -667,13 +685,14 @@ int ngp_distortion_loss_bw(const float* dL_dloss, const float* ws_inclusive_scan
     return ngp_check_launch();
 }
 
-int ngp_nerf_loss(const float* rgb, const float* target_rgb, const float* opacity, int n_rays, float lambda_opacity,
-                  float* sums, float* d_rgb, float* d_opacity, void* stream)
+int ngp_nerf_loss(const float* rgb, const float* target_rgb, const float* opacity, const float* distortion,
+                  int n_rays, float lambda_opacity, float lambda_distortion, float* terms, float* d_rgb,
+                  float* d_opacity, void* stream)
 {
-    if (n_rays < 1 || !rgb || !target_rgb || !opacity || !sums || !d_rgb || !d_opacity) return NGP_EINVAL;
+    if (n_rays < 1 || !rgb || !target_rgb || !opacity || !terms || !d_rgb || !d_opacity) return NGP_EINVAL;
     hipLaunchKernelGGL(nerf_loss_kernel, dim3(ngp_blocks(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, rgb,
-                       target_rgb, opacity, n_rays, 1.0f / (3.0f * n_rays), lambda_opacity / n_rays, sums, d_rgb,
-                       d_opacity);
+                       target_rgb, opacity, distortion, n_rays, 1.0f / (3.0f * n_rays), lambda_opacity / n_rays,
+                       lambda_distortion / n_rays, terms, d_rgb, d_opacity);
     return ngp_check_launch();
 }
 

@@ -475,6 +475,23 @@ __global__ void sh_fwd_kernel(const float* __restrict__ xin, int64_t n, float* _
     for (int k = 0; k < D; k++) y[i * ldy + k] = o[k];
 }
 
+// SH of a raw direction: d -> (normalize(d, eps 1e-6) + 1) / 2 -> basis, i.e. networks.py:198,222
+// (F.normalize, the [0,1] remap and the encoder) in one launch
+template <int DEG>
+__global__ void sh_fwd_dirs_kernel(const float* __restrict__ d, int64_t n, float* __restrict__ y, int64_t ldy)
+{
+    constexpr int D = DEG * DEG;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float dx = d[3 * i], dy = d[3 * i + 1], dz = d[3 * i + 2];
+    const float inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
+    const float ux = (dx * inv + 1.0f) * 0.5f, uy = (dy * inv + 1.0f) * 0.5f, uz = (dz * inv + 1.0f) * 0.5f;
+    float o[16];
+    sh_eval(ux * 2 - 1, uy * 2 - 1, uz * 2 - 1, DEG, o);
+#pragma unroll
+    for (int k = 0; k < D; k++) y[i * ldy + k] = o[k];
+}
+
 // dL_dx of the SH basis (includes the factor 2 of the [0,1] -> [-1,1] remap)
 template <int DEG>
 __global__ void sh_bwd_kernel(const float* __restrict__ xin, const float* __restrict__ dL_dy, int64_t n,
@@ -703,6 +720,22 @@ int ngp_sh_fwd(const float* x, int64_t n, int degree, float* y, int64_t ldy, voi
         case 2: hipLaunchKernelGGL(sh_fwd_kernel<2>, grid, dim3(256), 0, st, x, n, y, ldy); break;
         case 3: hipLaunchKernelGGL(sh_fwd_kernel<3>, grid, dim3(256), 0, st, x, n, y, ldy); break;
         default: hipLaunchKernelGGL(sh_fwd_kernel<4>, grid, dim3(256), 0, st, x, n, y, ldy); break;
+    }
+    return ngp_check_launch();
+}
+
+int ngp_sh_fwd_dirs(const float* d, int64_t n, int degree, float* y, int64_t ldy, void* stream)
+{
+    if (n < 0 || degree < 1 || degree > 4 || ldy < degree * degree) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!d || !y) return NGP_EINVAL;
+    const dim3 grid(ngp_blocks(n, 256));
+    hipStream_t st = (hipStream_t)stream;
+    switch (degree) {
+        case 1: hipLaunchKernelGGL(sh_fwd_dirs_kernel<1>, grid, dim3(256), 0, st, d, n, y, ldy); break;
+        case 2: hipLaunchKernelGGL(sh_fwd_dirs_kernel<2>, grid, dim3(256), 0, st, d, n, y, ldy); break;
+        case 3: hipLaunchKernelGGL(sh_fwd_dirs_kernel<3>, grid, dim3(256), 0, st, d, n, y, ldy); break;
+        default: hipLaunchKernelGGL(sh_fwd_dirs_kernel<4>, grid, dim3(256), 0, st, d, n, y, ldy); break;
     }
     return ngp_check_launch();
 }

@@ -89,8 +89,8 @@ class VolumeRenderer(torch.autograd.Function):
         nr = rays_a.shape[0]
         dev = sigmas.device
 
-        def z(t, *shape):
-            return torch.zeros(*shape, dtype=_f32, device=dev) if t is None else t.contiguous()
+        def z(t, *shape):   # the kernel reads a NULL upstream gradient as zeros
+            return None if t is None else t.contiguous()
 
         # The reference back-propagates all-zero gradients through the normal / semantic heads when
         # the loss ignores those maps; here they are simply not produced (None) and the field's

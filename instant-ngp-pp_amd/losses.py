@@ -43,33 +43,56 @@ class DistortionLoss(torch.autograd.Function):
         return dL_dws, None, None, None
 
 
+_CONST = {}
+
+
+def _const(value, n, device):
+    """cached (n,) tensor filled with `value` (upstream gradient of a mean over the rays)"""
+    key = (float(value), int(n), str(device))
+    t = _CONST.get(key)
+    if t is None:
+        if len(_CONST) > 64:
+            _CONST.clear()
+        t = _CONST[key] = torch.full((n,), float(value), dtype=torch.float32, device=device)
+    return t
+
+
+@torch.no_grad()
+def nerf_loss_and_grads(rgb, opacity, ws, deltas, ts, rays_a, target_rgb, lambda_opa, lambda_distortion):
+    """sum(term.mean()) over NeRFLoss's default terms — rgb MSE, opacity entropy, distortion
+    (losses.py:96-105, train.py:307) — together with its gradients, in four launches.
+    -> terms (4) = [loss, rgb, opacity, distortion], (d_rgb (N_rays,3), d_opacity (N_rays), d_ws (N) or None)
+    rays_a must cover every sample row (the marcher's output does)."""
+    from ._lib import call
+    nr, N = rgb.shape[0], ws.shape[0]
+    dev = rgb.device
+    rgb, opacity, ws = rgb.contiguous(), opacity.contiguous(), ws.contiguous()
+    terms = torch.zeros(4, dtype=torch.float32, device=dev)
+    d_rgb = torch.empty(nr, 3, dtype=torch.float32, device=dev)
+    d_op = torch.empty(nr, dtype=torch.float32, device=dev)
+    dist = d_ws = None
+    if lambda_distortion > 0:
+        dist = torch.empty(nr, dtype=torch.float32, device=dev)
+        wi = torch.empty(N, dtype=torch.float32, device=dev)
+        wti = torch.empty(N, dtype=torch.float32, device=dev)
+        call("distortion_loss_fw", ws, deltas, ts, rays_a, nr, dist, wi, wti)
+        d_ws = torch.empty(N, dtype=torch.float32, device=dev)
+        call("distortion_loss_bw", _const(lambda_distortion / nr, nr, dev), wi, wti, ws, deltas, ts, rays_a, nr, d_ws)
+    call("nerf_loss", rgb, target_rgb.contiguous(), opacity, dist, nr, float(lambda_opa), float(lambda_distortion),
+         terms, d_rgb, d_op)
+    return terms, (d_rgb, d_op, d_ws)
+
+
 class FusedNeRFLoss(torch.autograd.Function):
-    """sum(term.mean()) of NeRFLoss's default terms — rgb MSE, opacity entropy, distortion
-    (losses.py:96-105, train.py:307) — with the gradients produced in the same three launches.
+    """autograd wrapper of nerf_loss_and_grads.
     Returns (loss, rgb_mse_mean, opacity_mean, distortion_mean); only `loss` is differentiable."""
 
     @staticmethod
     def forward(ctx, rgb, opacity, ws, deltas, ts, rays_a, target_rgb, lambda_opa, lambda_distortion):
-        from ._lib import call
-        nr = rgb.shape[0]
-        dev = rgb.device
-        rgb, opacity, ws = rgb.contiguous(), opacity.contiguous(), ws.contiguous()
-        sums = torch.zeros(2, dtype=torch.float32, device=dev)
-        d_rgb = torch.empty(nr, 3, dtype=torch.float32, device=dev)
-        d_op = torch.empty(nr, dtype=torch.float32, device=dev)
-        call("nerf_loss", rgb, target_rgb.contiguous(), opacity, nr, float(lambda_opa), sums, d_rgb, d_op)
-        t_rgb = sums[0] / (3 * nr)
-        t_op = sums[1] * (lambda_opa / nr)
-        loss = t_rgb + t_op
-        d_ws = None
-        t_dist = torch.zeros((), dtype=torch.float32, device=dev)
-        if lambda_distortion > 0:
-            dist, wi, wti = vren.distortion_loss_fw(ws, deltas, ts, rays_a)
-            t_dist = dist.mean() * lambda_distortion
-            loss = loss + t_dist
-            g = torch.full((nr,), lambda_distortion / nr, dtype=torch.float32, device=dev)
-            d_ws = vren.distortion_loss_bw(g, wi, wti, ws, deltas, ts, rays_a)
+        terms, (d_rgb, d_op, d_ws) = nerf_loss_and_grads(rgb, opacity, ws, deltas, ts, rays_a, target_rgb, lambda_opa,
+                                                         lambda_distortion)
         ctx.save_for_backward(d_rgb, d_op, d_ws)
+        loss, t_rgb, t_op, t_dist = terms.unbind(0)
         ctx.mark_non_differentiable(t_rgb, t_op, t_dist)
         return loss, t_rgb, t_op, t_dist
 

@@ -201,8 +201,7 @@ class _FieldFn(Function):
 
         # colour branch: [SH(16) | rgb grid features (128) | appearance code (E) | ones-padding]
         rgb_in = torch.empty(n, Kp, dtype=_f32, device=dev)
-        dn = F.normalize(d, p=2, dim=-1, eps=1e-6)
-        call("sh_fwd", ((dn + 1) / 2).contiguous(), n, 4, rgb_in, Kp)
+        call("sh_fwd_dirs", d, n, 4, rgb_in, Kp)
         _wait_params(model)   # the colour table's Adam piece ran under the density path above
         call("grid_fwd", re.desc, rgb_table, xn, n, rgb_in[:, 16:], Kp)
         if E:

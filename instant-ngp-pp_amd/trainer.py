@@ -24,7 +24,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import call
-from .losses import FusedNeRFLoss, NeRFLoss
+from .losses import NeRFLoss, nerf_loss_and_grads
 from .rendering import MAX_SAMPLES, MarchAhead, render
 
 _f32 = torch.float32
@@ -221,14 +221,21 @@ class NGPTrainer:
         results = render(model, rays_o, rays_d, exp_step_factor=self.exp_step_factor,
                          num_classes=self.num_classes, marched=marched, **self.render_kwargs)
         if self.fused_loss:
-            # same value and gradients as sum(term.mean()) over NeRFLoss's default terms
-            loss, *_terms = FusedNeRFLoss.apply(results["rgb"], results["opacity"], results["ws"], results["deltas"],
-                                                results["ts"], results["rays_a"], rgb_gt, self.loss_fn.lambda_opa,
-                                                self.loss_fn.lambda_distortion)
+            # same value and gradients as sum(term.mean()) over NeRFLoss's default terms; the
+            # gradients are seeded directly (no loss node, no multiplications by 1)
+            terms, (d_rgb, d_op, d_ws) = nerf_loss_and_grads(
+                results["rgb"], results["opacity"], results["ws"], results["deltas"], results["ts"],
+                results["rays_a"], rgb_gt, self.loss_fn.lambda_opa, self.loss_fn.lambda_distortion)
+            loss = terms[0]
+            outs, seeds = [results["rgb"], results["opacity"]], [d_rgb, d_op]
+            if d_ws is not None:
+                outs.append(results["ws"])
+                seeds.append(d_ws)
+            torch.autograd.backward(outs, seeds)
         else:
             loss_d = self.loss_fn(results, {"rgb": rgb_gt})
             loss = sum(lo.mean() for lo in loss_d.values())
-        loss.backward()
+            loss.backward()
         self.optimizer_step()
         return loss.detach(), results
 

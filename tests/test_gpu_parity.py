@@ -826,6 +826,20 @@ def test_fused_loss_matches_nerfloss(ngp):
     assert abs(outs[0][0] - outs[1][0]) < 1e-6 * max(1.0, abs(outs[0][0]))
     for a, b in zip(outs[0][1], outs[1][1]):
         close(b, a, 1e-4, 1e-9)
+    # the trainer seeds backward with these directly; terms = [loss, rgb, opacity, distortion]
+    from ngp_amd.losses import nerf_loss_and_grads
+    terms, (d_rgb, d_op, d_ws) = nerf_loss_and_grads(T(outs[0][3]), T(outs[0][4]), T(ws0), T(deltas), T(ts), T(rays_a),
+                                                    gt, 2e-4, 3e-4)
+    terms = N(terms)
+    assert abs(terms[0] - outs[0][0]) < 1e-6 * max(1.0, abs(outs[0][0]))
+    assert abs(terms[1] + terms[2] + terms[3] - terms[0]) < 1e-6
+    for a, b in zip(outs[0][1], (d_rgb, d_op, d_ws)):
+        close(N(b), a, 1e-4, 1e-9)
+    # without the distortion term
+    terms0, (_, _, d_ws0) = nerf_loss_and_grads(T(outs[0][3]), T(outs[0][4]), T(ws0), T(deltas), T(ts), T(rays_a),
+                                               gt, 2e-4, 0.0)
+    assert d_ws0 is None and abs(float(terms0[3])) == 0.0
+    assert abs(float(terms0[0]) - (terms[1] + terms[2])) < 1e-6
 
 
 def test_neg_normalize_and_refloss_inputs(ngp):
