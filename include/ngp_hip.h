@@ -321,6 +321,21 @@ int ngp_mlp_hidden_bwd(const float* dOut, int64_t lddo, const float* out, int64_
                        int64_t n, int H, int n_out, float* dz2, int64_t lddz2,
                        float* dz1, int64_t lddz1, void* stream);
 
+/* Backward of the FIRST layer of a 2-layer MLP  x -> hidden = act1(x W1^T + b1) -> out = act2(hidden W2^T + b2)
+ * (n_out <= 4: xyz_net, rgb_net, norm_pred_header) with the hidden-layer gradient
+ *     dz1 = act1'(hidden) * (dz2 . W2),   dz2 (n, n_out) = dL/dout * act2'(out)  [ngp_act_bwd]
+ * formed inside the MFMA product while its operand tile is staged, so that dz1 is never written to or
+ * read from HBM (it is n x 128 floats, and the plain route ngp_mlp_hidden_bwd -> ngp_linear_bwd_*
+ * moves it three times):
+ *   ngp_mlp_bwd_input : dx (n, n_in) (+)= dz1 . W1[:, :n_in]
+ *   ngp_mlp_bwd_weight: dW1 (H, n_in) += dz1^T . x,  db1 (H) += column sums of dz1 (db1 may be NULL) */
+int ngp_mlp_bwd_input(const float* dz2, int64_t lddz2, const float* W2, int64_t ldw2, const float* hidden,
+                      int64_t ldh, int act1, const float* W1, int64_t ldw1, int64_t n, int n_in, int H,
+                      int n_out, float* dx, int64_t lddx, int accumulate, void* stream);
+int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t ldw2, const float* hidden,
+                       int64_t ldh, int act1, const float* x, int64_t ldx, int64_t n, int n_in, int H,
+                       int n_out, float* dW1, int64_t ldw, float* db1, void* stream);
+
 /* ------------------------------------------------------------------------
  * fused Adam step (torch.optim.Adam(eps=1e-8) semantics, train.py:244) over one
  * flat fp32 tensor; optionally scales the gradient first (grad clipping /

@@ -31,6 +31,12 @@ struct GemmArgs {
     int vecA, vecB;       // 16-byte vector loads legal for the operand
     int accumulate;       // DGRAD: C += result
     float* bias_grad;     // WGRAD: db[m] += sum_k dz[k][m] (may be null)
+    // XF kernels (DGRAD / WGRAD of the FIRST layer of a 2-layer MLP): A points at the saved hidden
+    // activations and the operand dz1 = act1'(hidden) * (dz2 . W2) is formed while the tile is
+    // staged, so dz1 never exists in HBM.  dz2 (rows, xf_nout) already carries act2'.
+    const float* xf_dz2; int64_t xf_lddz2;
+    const float* xf_W2; int64_t xf_ldw2;
+    int xf_nout, xf_act;
 };
 
 // softplus(v) = log(1+e^v) with the hardware exp/log (v_exp_f32 / v_log_f32, ~1e-6 relative):
@@ -52,7 +58,26 @@ __device__ __forceinline__ float act_fwd(float v, int act)
     }
 }
 
+__device__ __forceinline__ float act_grad_from_output(float y, int act)
+{
+    switch (act) {
+        case NGP_ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
+        case NGP_ACT_SIGMOID: return y * (1.0f - y);
+        case NGP_ACT_SOFTPLUS: return -expm1f(-y);
+        case NGP_ACT_EXP: return y;
+        default: return 1.0f;
+    }
+}
+
+// derivative through the OUTPUT for the two hidden activations of the model, cheap enough for the
+// staging path of a GEMM (softplus' = 1 - exp(-y), v_exp_f32)
+__device__ __forceinline__ float act_grad_fast(float y, int act)
+{
+    return act == NGP_ACT_SOFTPLUS ? 1.0f - __expf(-y) : (act == NGP_ACT_RELU ? (y > 0.0f ? 1.0f : 0.0f) : act_grad_from_output(y, act));
+}
+
 constexpr int BK = 32;
+constexpr int XF_OMAX = 4;   // widest second layer the fused operand transform handles
 
 // Global -> register fetch and register -> LDS commit are separate so that the fetch of K-tile
 // t+1 is in flight while the MFMAs of tile t run (register double buffering; one LDS buffer).
@@ -86,6 +111,43 @@ struct TileT {
                     for (int j = 0; j < 4; j++) if (gk + j < kend) v[pass][j] = p[j];
                 }
             }
+        }
+    }
+    // XF: v holds hidden[row][k..k+3]; dz1 = act1'(hidden) * sum_o dz2[row][o] W2[o][k].
+    // xf_fetch issues the (prefetchable) loads of dz2 / W2 next to the tile's own, xform is pure ALU.
+    float d2[PASSES][XF_OMAX];
+    float w2[XF_OMAX][4];
+    template <int OM, class ArgsT>
+    __device__ __forceinline__ void xf_fetch(const ArgsT& p, int64_t row0, int64_t rows, int64_t k0, int64_t kend)
+    {
+        const int t = threadIdx.x;
+        const int64_t gk = k0 + (t % KQ) * 4;
+#pragma unroll
+        for (int o = 0; o < OM; o++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                w2[o][j] = (o < p.xf_nout && gk + j < kend) ? p.xf_W2[o * p.xf_ldw2 + gk + j] : 0.0f;
+#pragma unroll
+        for (int pass = 0; pass < PASSES; pass++) {
+            const int row = t / KQ + pass * RPP;
+            const int64_t gr = row0 + row;
+#pragma unroll
+            for (int o = 0; o < OM; o++)
+                d2[pass][o] = (row < ROWS && gr < rows && o < p.xf_nout) ? p.xf_dz2[gr * p.xf_lddz2 + o] : 0.0f;
+        }
+    }
+    template <int OM>
+    __device__ __forceinline__ void xform(int act)
+    {
+#pragma unroll
+        for (int pass = 0; pass < PASSES; pass++) {
+            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int o = 0; o < OM; o++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) s[j] = fmaf(d2[pass][o], w2[o][j], s[j]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[pass][j] = s[j] * act_grad_fast(v[pass][j], act);
         }
     }
     // dst[k][row], k-major with leading dimension LD
@@ -136,6 +198,42 @@ struct TileD {
             }
         }
     }
+    // XF: v holds hidden[k][col..col+3] (k = sample row); W2's columns are fixed per thread
+    float d2[PASSES][XF_OMAX];
+    float w2[XF_OMAX][4];
+    template <int OM, class ArgsT>
+    __device__ __forceinline__ void xf_fetch(const ArgsT& p, int64_t col0, int64_t cols, int64_t k0, int64_t kend)
+    {
+        const int t = threadIdx.x;
+        const int64_t gc = col0 + (t % TPR) * 4;
+#pragma unroll
+        for (int o = 0; o < OM; o++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                w2[o][j] = (o < p.xf_nout && gc + j < cols) ? p.xf_W2[o * p.xf_ldw2 + gc + j] : 0.0f;
+#pragma unroll
+        for (int pass = 0; pass < PASSES; pass++) {
+            const int kr = t / TPR + pass * RPP;
+            const int64_t gk = k0 + kr;
+#pragma unroll
+            for (int o = 0; o < OM; o++)
+                d2[pass][o] = (kr < BK && gk < kend && o < p.xf_nout) ? p.xf_dz2[gk * p.xf_lddz2 + o] : 0.0f;
+        }
+    }
+    template <int OM>
+    __device__ __forceinline__ void xform(int act)
+    {
+#pragma unroll
+        for (int pass = 0; pass < PASSES; pass++) {
+            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int o = 0; o < OM; o++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) s[j] = fmaf(d2[pass][o], w2[o][j], s[j]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[pass][j] = s[j] * act_grad_fast(v[pass][j], act);
+        }
+    }
     template <int LD>
     __device__ __forceinline__ void commit(float* __restrict__ dst) const
     {
@@ -155,9 +253,10 @@ struct TileD {
 template <bool TRANSPOSED, int EXT> struct TileSel { typedef TileT<EXT> type; };
 template <int EXT> struct TileSel<false, EXT> { typedef TileD<EXT> type; };
 
-template <int MODE, int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs p)
+template <int MODE, int WM, int WN, int TM, int TN, int XF>   // XF = width of the fused second layer (0: plain)
+__device__ __forceinline__ void gemm_body(const GemmArgs& p)
 {
+    static_assert(!XF || MODE != MODE_FWD, "the operand transform exists for DGRAD / WGRAD only");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int LDA = BM + 2, LDB = BN + 2;
     __shared__ float As[BK * LDA];
@@ -189,13 +288,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs p)
     const bool want_db = MODE == MODE_WGRAD && p.bias_grad != nullptr && blockIdx.y == 0;
 
     ta.fetch(p.A, p.lda, m0, p.M, kbeg, kend, p.vecA);
+    if (XF) ta.template xf_fetch<XF>(p, m0, p.M, kbeg, kend);
     tb.fetch(p.B, p.ldb, n0, p.N, kbeg, kend, p.vecB);
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        if (XF) ta.template xform<XF>(p.xf_act);   // hidden -> dz1 in registers, on its way to LDS
         ta.template commit<LDA>(As);
         tb.template commit<LDB>(Bs);
         __syncthreads();
         if (k0 + BK < kend) {
             ta.fetch(p.A, p.lda, m0, p.M, k0 + BK, kend, p.vecA);
+            if (XF) ta.template xf_fetch<XF>(p, m0, p.M, k0 + BK, kend);
             tb.fetch(p.B, p.ldb, n0, p.N, k0 + BK, kend, p.vecB);
         }
         if (want_db && threadIdx.x < BM) {
@@ -243,6 +345,19 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs p)
                 }
             }
         }
+}
+
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs p)
+{
+    gemm_body<MODE, WM, WN, TM, TN, 0>(p);
+}
+
+// operand-transform variant: the extra staging registers must not cost the third workgroup per CU
+template <int MODE, int WM, int WN, int TM, int TN, int XF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) gemm_xf_kernel(GemmArgs p)
+{
+    gemm_body<MODE, WM, WN, TM, TN, XF>(p);
 }
 
 // ---------------------------------------------------------------- skinny layers (n_out <= 4)
@@ -408,7 +523,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const float g = dy[i];
+        const float g = dy ? dy[i] : 1.0f;
         float v;
         switch (act) {
             case NGP_ACT_RELU: v = yz[i] > 0.0f ? g : 0.0f; break;
@@ -423,16 +538,6 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 
 
 // derivative of an activation expressed through its OUTPUT y
-__device__ __forceinline__ float act_grad_from_output(float y, int act)
-{
-    switch (act) {
-        case NGP_ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
-        case NGP_ACT_SIGMOID: return y * (1.0f - y);
-        case NGP_ACT_SOFTPLUS: return -expm1f(-y);
-        case NGP_ACT_EXP: return y;
-        default: return 1.0f;
-    }
-}
 
 // Hidden-layer backward of a 2-layer MLP whose output layer is narrow (n_out <= 16):
 //   dz2[n][o] = dOut[n][o] * act2'(out[n][o])          (written to dz2, row stride lddz2)
@@ -581,6 +686,61 @@ __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+#define LAUNCH_GEMM(MODE, WM, WN, TM, TN)                                                                   \
+    do {                                                                                                   \
+        if (XF == 0) hipLaunchKernelGGL((gemm_kernel<MODE, WM, WN, TM, TN>), grid, dim3(256), 0, st, p);      \
+        else hipLaunchKernelGGL((gemm_xf_kernel<MODE, WM, WN, TM, TN, (XF ? XF : 1)>), grid, dim3(256), 0, st, p); \
+    } while (0)
+
+// C (M, N) = A (M, K) . B (K, N): 128-wide tiles when the output is wider than 32 columns
+template <int XF>
+void launch_dgrad(const GemmArgs& p, hipStream_t st)
+{
+    if (p.N > 32) {
+        dim3 grid(ngp_blocks(p.M, 128), ngp_blocks(p.N, 128));
+        LAUNCH_GEMM(MODE_DGRAD, 2, 2, 2, 2);
+    } else {
+        dim3 grid(ngp_blocks(p.M, 128), 1);
+        LAUNCH_GEMM(MODE_DGRAD, 4, 1, 1, 1);
+    }
+}
+
+// C (M, N) += A^T . B over K = samples, split so that one full wave of workgroups (3 per CU) is in flight
+template <int XF>
+void launch_wgrad(GemmArgs p, hipStream_t st)
+{
+    const int64_t n = p.K;
+    const bool big_m = p.M > 32, big_n = p.N > 32;
+    const int64_t tiles = (int64_t)ngp_blocks(p.M, big_m ? 128 : 32) * ngp_blocks(p.N, big_n ? 128 : 32);
+    static const int target_blocks = getenv("NGP_WGRAD_BLOCKS") ? atoi(getenv("NGP_WGRAD_BLOCKS")) : 768; // 3 workgroups per CU x 256 CUs
+    int64_t splits = target_blocks / (tiles > 0 ? tiles : 1);
+    if (splits < 1) splits = 1;
+    int64_t chunk = (n + splits - 1) / splits;
+    chunk = (chunk + BK - 1) / BK * BK;
+    if (chunk < 256) chunk = 256;
+    splits = (n + chunk - 1) / chunk;
+    p.k_chunk = chunk;
+    if (big_m && big_n) {
+        dim3 grid(ngp_blocks(p.M, 128), ngp_blocks(p.N, 128), (unsigned)splits);
+        LAUNCH_GEMM(MODE_WGRAD, 2, 2, 2, 2);
+    } else if (big_m) { // tall: 128 x 32 tiles
+        dim3 grid(ngp_blocks(p.M, 128), ngp_blocks(p.N, 32), (unsigned)splits);
+        LAUNCH_GEMM(MODE_WGRAD, 4, 1, 1, 1);
+    } else if (big_n) { // wide: 32 x 128 tiles
+        dim3 grid(ngp_blocks(p.M, 32), ngp_blocks(p.N, 128), (unsigned)splits);
+        LAUNCH_GEMM(MODE_WGRAD, 1, 4, 1, 1);
+    } else {
+        dim3 grid(ngp_blocks(p.M, 64), ngp_blocks(p.N, 64), (unsigned)splits);
+        LAUNCH_GEMM(MODE_WGRAD, 2, 2, 1, 1);
+    }
+}
+
+inline bool xf_args_ok(const float* dz2, int64_t lddz2, const float* W2, int64_t ldw2, const float* hidden,
+                       int64_t ldh, int H, int n_out)
+{
+    return dz2 && W2 && hidden && n_out >= 1 && n_out <= XF_OMAX && lddz2 >= n_out && ldw2 >= H && ldh >= H && H >= 8;
+}
+
 } // namespace
 
 extern "C" {
@@ -628,13 +788,7 @@ int ngp_linear_bwd_input(const float* dz, int64_t lddz, const float* W, int64_t 
     p.A = dz; p.lda = lddz; p.B = W; p.ldb = ldw; p.C = dx; p.ldc = lddx;
     p.M = n; p.N = n_in; p.K = n_out; p.act = 0; p.k_chunk = 0; p.accumulate = accumulate;
     p.vecA = aligned16(dz) && (lddz % 4 == 0); p.vecB = aligned16(W) && (ldw % 4 == 0);
-    if (n_in > 32) {
-        dim3 grid(ngp_blocks(n, 128), ngp_blocks(n_in, 128));
-        hipLaunchKernelGGL((gemm_kernel<MODE_DGRAD, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
-    } else {
-        dim3 grid(ngp_blocks(n, 128), 1);
-        hipLaunchKernelGGL((gemm_kernel<MODE_DGRAD, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
-    }
+    launch_dgrad<0>(p, st);
     return ngp_check_launch();
 }
 
@@ -658,30 +812,7 @@ int ngp_linear_bwd_weight(const float* dz, int64_t lddz, const float* x, int64_t
     p.A = dz; p.lda = lddz; p.B = x; p.ldb = ldx; p.C = dW; p.ldc = ldw;
     p.M = n_out; p.N = n_in; p.K = n; p.act = 0; p.bias_grad = db;
     p.vecA = aligned16(dz) && (lddz % 4 == 0); p.vecB = aligned16(x) && (ldx % 4 == 0);
-    // split the sample dimension so that one full wave of workgroups (3 per CU) is in flight
-    const bool big_m = n_out > 32, big_n = n_in > 32;
-    const int64_t tiles = (int64_t)ngp_blocks(n_out, big_m ? 128 : 32) * ngp_blocks(n_in, big_n ? 128 : 32);
-    static const int target_blocks = getenv("NGP_WGRAD_BLOCKS") ? atoi(getenv("NGP_WGRAD_BLOCKS")) : 768; // 3 workgroups per CU x 256 CUs
-    int64_t splits = target_blocks / (tiles > 0 ? tiles : 1);
-    if (splits < 1) splits = 1;
-    int64_t chunk = (n + splits - 1) / splits;
-    chunk = (chunk + BK - 1) / BK * BK;
-    if (chunk < 256) chunk = 256;
-    splits = (n + chunk - 1) / chunk;
-    p.k_chunk = chunk;
-    if (big_m && big_n) {
-        dim3 grid(ngp_blocks(n_out, 128), ngp_blocks(n_in, 128), (unsigned)splits);
-        hipLaunchKernelGGL((gemm_kernel<MODE_WGRAD, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
-    } else if (big_m) { // tall: 128 x 32 tiles
-        dim3 grid(ngp_blocks(n_out, 128), ngp_blocks(n_in, 32), (unsigned)splits);
-        hipLaunchKernelGGL((gemm_kernel<MODE_WGRAD, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
-    } else if (big_n) { // wide: 32 x 128 tiles
-        dim3 grid(ngp_blocks(n_out, 32), ngp_blocks(n_in, 128), (unsigned)splits);
-        hipLaunchKernelGGL((gemm_kernel<MODE_WGRAD, 1, 4, 1, 1>), grid, dim3(256), 0, st, p);
-    } else {
-        dim3 grid(ngp_blocks(n_out, 64), ngp_blocks(n_in, 64), (unsigned)splits);
-        hipLaunchKernelGGL((gemm_kernel<MODE_WGRAD, 2, 2, 1, 1>), grid, dim3(256), 0, st, p);
-    }
+    launch_wgrad<0>(p, st);
     return ngp_check_launch();
 }
 
@@ -689,7 +820,7 @@ int ngp_act_bwd(const float* dy, const float* y_or_z, int64_t count, int activat
 {
     if (count < 0) return NGP_EINVAL;
     if (count == 0) return NGP_OK;
-    if (!dy || !dz || (activation != NGP_ACT_NONE && !y_or_z)) return NGP_EINVAL;
+    if (!dz || (activation != NGP_ACT_NONE && !y_or_z)) return NGP_EINVAL;   // dy == NULL: all ones
     int64_t blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y_or_z, count,
@@ -715,6 +846,44 @@ int ngp_mlp_hidden_bwd(const float* dOut, int64_t lddo, const float* out, int64_
     else
         hipLaunchKernelGGL(mlp_hidden_bwd_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, dOut, lddo, out, ldo, act2,
                            W2, ldw2, hidden, ldh, act1, n, H, n_out, dz2, lddz2, dz1, lddz1);
+    return ngp_check_launch();
+}
+
+int ngp_mlp_bwd_input(const float* dz2, int64_t lddz2, const float* W2, int64_t ldw2, const float* hidden,
+                      int64_t ldh, int act1, const float* W1, int64_t ldw1, int64_t n, int n_in, int H, int n_out,
+                      float* dx, int64_t lddx, int accumulate, void* stream)
+{
+    if (n < 0 || n_in < 1 || !xf_args_ok(dz2, lddz2, W2, ldw2, hidden, ldh, H, n_out) || ldw1 < n_in || lddx < n_in)
+        return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!W1 || !dx) return NGP_EINVAL;
+    GemmArgs p{};
+    p.A = hidden; p.lda = ldh; p.B = W1; p.ldb = ldw1; p.C = dx; p.ldc = lddx;
+    p.M = n; p.N = n_in; p.K = H; p.accumulate = accumulate;
+    p.vecA = aligned16(hidden) && (ldh % 4 == 0); p.vecB = aligned16(W1) && (ldw1 % 4 == 0);
+    p.xf_dz2 = dz2; p.xf_lddz2 = lddz2; p.xf_W2 = W2; p.xf_ldw2 = ldw2; p.xf_nout = n_out; p.xf_act = act1;
+    if (n_out == 1) launch_dgrad<1>(p, (hipStream_t)stream);
+    else if (n_out <= 3) launch_dgrad<3>(p, (hipStream_t)stream);
+    else launch_dgrad<XF_OMAX>(p, (hipStream_t)stream);
+    return ngp_check_launch();
+}
+
+int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t ldw2, const float* hidden,
+                       int64_t ldh, int act1, const float* x, int64_t ldx, int64_t n, int n_in, int H, int n_out,
+                       float* dW1, int64_t ldw, float* db1, void* stream)
+{
+    if (n < 0 || n_in < 1 || !xf_args_ok(dz2, lddz2, W2, ldw2, hidden, ldh, H, n_out) || ldx < n_in || ldw < n_in)
+        return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!x || !dW1) return NGP_EINVAL;
+    GemmArgs p{};
+    p.A = hidden; p.lda = ldh; p.B = x; p.ldb = ldx; p.C = dW1; p.ldc = ldw;
+    p.M = H; p.N = n_in; p.K = n; p.bias_grad = db1;
+    p.vecA = aligned16(hidden) && (ldh % 4 == 0); p.vecB = aligned16(x) && (ldx % 4 == 0);
+    p.xf_dz2 = dz2; p.xf_lddz2 = lddz2; p.xf_W2 = W2; p.xf_ldw2 = ldw2; p.xf_nout = n_out; p.xf_act = act1;
+    if (n_out == 1) launch_wgrad<1>(p, (hipStream_t)stream);
+    else if (n_out <= 3) launch_wgrad<3>(p, (hipStream_t)stream);
+    else launch_wgrad<XF_OMAX>(p, (hipStream_t)stream);
     return ngp_check_launch();
 }
 

@@ -75,6 +75,11 @@ _RELU, _NONE = 1, 0
 import os as _os
 
 _OVERLAP = _os.environ.get("NGP_NO_OVERLAP", "0") != "1"
+_FUSED_BWD = _os.environ.get("NGP_NO_FUSED_BWD", "0") != "1"   # A/B switch for the operand-transform products
+# widest second layer that takes the fused route: measured on MI355X (tools/mlp_bwd_microbench.py,
+# n = 433 k) the density head (1 output) gains 16 % (0.53 -> 0.45 ms), 3 outputs lose 6 % (the
+# extra staging registers spill at 3 workgroups per CU), so rgb_net and the headers stay on the plain route
+_FUSED_BWD_MAX_OUT = int(_os.environ.get("NGP_FUSED_BWD_MAX_OUT", "1"))
 _SIDE = {}
 
 
@@ -93,6 +98,29 @@ def _mlp2_backward(d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, l
     dx receives dz1 . W1[:, w1_col0 : w1_col0+dx_cols] (the input columns that need a gradient)."""
     n = hidden.shape[0]
     dev = hidden.device
+    w1_dx = W1[w1_col0:] if W1.dim() == 1 else W1
+    wide = n_in > 128 and n_in % 128 <= 32
+    # 128 + remainder columns: a second launch with 128x32 tiles instead of a mostly empty 128x128
+    # tile (rgb_net's first layer is 128 x 144/160)
+    rem = n_in - 128
+    x_rem = x_in[:, 128:] if x_in.dim() == 2 else x_in
+    dW1_rem = dW1[128:] if dW1.dim() == 1 else dW1[:, 128:]
+    if _FUSED_BWD and n_out <= _FUSED_BWD_MAX_OUT and d_out.stride(0) == n_out and ld_out == n_out:
+        # dz1 = act1'(hidden) * (dz2 . W2) is formed inside the two first-layer products
+        dz2 = torch.empty(n, n_out, dtype=_f32, device=dev)
+        call("act_bwd", d_out, out, n * n_out, act2, dz2)
+        call("linear_bwd_weight", dz2, n_out, hidden, H, n, H, n_out, dW2, H, db2)
+        if before_products is not None:
+            before_products()
+        if wide:
+            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, 128, H, n_out, dW1, ldw1, db1)
+            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_rem, ld_in, n, rem, H, n_out, dW1_rem, ldw1, None)
+        else:
+            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, n_in, H, n_out, dW1, ldw1, db1)
+        if dx is not None:
+            call("mlp_bwd_input", dz2, n_out, W2, H, hidden, H, act1, w1_dx, ldw1, n, dx_cols, H, n_out, dx, ld_dx,
+                 1 if accumulate else 0)
+        return
     dz2 = torch.empty(n, 16 if n_out > 4 else 4, dtype=_f32, device=dev)
     dz1 = torch.empty(n, H, dtype=_f32, device=dev)
     call("mlp_hidden_bwd", d_out, d_out.stride(0), out, ld_out, act2, W2, H, hidden, H, act1, n, H, n_out,
@@ -100,20 +128,13 @@ def _mlp2_backward(d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, l
     call("linear_bwd_weight", dz2, dz2.shape[1], hidden, H, n, H, n_out, dW2, H, db2)
     if before_products is not None:
         before_products()
-    if n_in > 128 and n_in % 128 <= 32:
-        # 128 + remainder columns: a second launch with 128x32 tiles instead of a mostly empty
-        # 128x128 tile (rgb_net's first layer is 128 x 144)
+    if wide:
         call("linear_bwd_weight", dz1, H, x_in, ld_in, n, 128, H, dW1, ldw1, db1)
-        rem = n_in - 128
-        x_rem = x_in[:, 128:] if x_in.dim() == 2 else x_in
-        call("linear_bwd_weight", dz1, H, x_rem, ld_in, n, rem, H, dW1[128:] if dW1.dim() == 1 else dW1[:, 128:],
-             ldw1, None)
+        call("linear_bwd_weight", dz1, H, x_rem, ld_in, n, rem, H, dW1_rem, ldw1, None)
     else:
         call("linear_bwd_weight", dz1, H, x_in, ld_in, n, n_in, H, dW1, ldw1, db1)
     if dx is not None:
-        call("linear_bwd_input", dz1, H, W1[w1_col0:] if W1.dim() == 1 else W1, ldw1, n, dx_cols, H, dx, ld_dx,
-             1 if accumulate else 0)
-    return dz1
+        call("linear_bwd_input", dz1, H, w1_dx, ldw1, n, dx_cols, H, dx, ld_dx, 1 if accumulate else 0)
 
 
 class _NegNormalize(Function):
@@ -191,10 +212,16 @@ class _FieldFn(Function):
         sig = torch.empty(n, 1, dtype=_f32, device=dev)
         call("linear_fwd", a1, 128, W2, 128, b2, n, 128, 1, _SOFTPLUS, sig, 1, None)
         # analytic d(sigma)/dx: back-substitute ones through the head, then the grid input gradient
-        dz1 = torch.empty(n, 128, dtype=_f32, device=dev)
-        call("mlp_hidden_bwd", None, 0, sig, 1, _SOFTPLUS, W2, 128, a1, 128, _SOFTPLUS, n, 128, 1, None, 0, dz1, 128)
         dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
-        call("linear_bwd_input", dz1, 128, W1, 128, n, 128, 128, dfeat, 128, 0)
+        if _FUSED_BWD:
+            dz2 = torch.empty(n, 1, dtype=_f32, device=dev)
+            call("act_bwd", None, sig, n, _SOFTPLUS, dz2)          # upstream gradient = ones
+            call("mlp_bwd_input", dz2, 1, W2, 128, a1, 128, _SOFTPLUS, W1, 128, n, 128, 128, 1, dfeat, 128, 0)
+            dz1 = None
+        else:
+            dz1 = torch.empty(n, 128, dtype=_f32, device=dev)
+            call("mlp_hidden_bwd", None, 0, sig, 1, _SOFTPLUS, W2, 128, a1, 128, _SOFTPLUS, n, 128, 1, None, 0, dz1, 128)
+            call("linear_bwd_input", dz1, 128, W1, 128, n, 128, 128, dfeat, 128, 0)
         grads = torch.empty(n, 3, dtype=_f32, device=dev)   # d sigma / d xn (normalised coordinates)
         call("grid_bwd_input", xe.desc, xyz_table, xn, dfeat, 128, n, grads)
         del dz1, dfeat

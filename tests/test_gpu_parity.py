@@ -472,6 +472,47 @@ def test_adam_matches_torch(ngp):
     close(N(p), N(p_ref), 1e-5, 1e-6)
 
 
+@pytest.mark.parametrize("case", [
+    # n, H, n_in, n_out, act1
+    (1000, 128, 128, 1, 3),     # density head: softplus hidden, one output
+    (1531, 128, 144, 3, 1),     # rgb_net: ReLU hidden, 144 (not a multiple of the tile) inputs
+    (777, 32, 128, 3, 1),       # norm_pred_header
+    (64, 128, 16, 4, 1),        # narrow input, fewer rows than one tile
+])
+def test_mlp_fused_first_layer_backward(ngp, case):
+    """ngp_mlp_bwd_input / ngp_mlp_bwd_weight (dz1 formed inside the MFMA product) against fp64:
+    dz1 = act1'(hidden) * (dz2 . W2), dx = dz1 . W1, dW1 = dz1^T . x, db1 = colsum(dz1)."""
+    from ngp_amd._lib import call
+    n, H, n_in, n_out, act1 = case
+    g = rng(300 + n)
+    z = g.normal(size=(n, H)).astype(np.float32)
+    hidden = np.log1p(np.exp(z)).astype(np.float32) if act1 == 3 else np.maximum(z, 0).astype(np.float32)
+    dz2 = g.normal(size=(n, n_out)).astype(np.float32)
+    W2 = g.normal(size=(n_out, H)).astype(np.float32)
+    W1 = g.normal(size=(H, n_in)).astype(np.float32)
+    x = g.normal(size=(n, n_in)).astype(np.float32)
+    d = (1 - np.exp(-hidden.astype(np.float64))) if act1 == 3 else (hidden > 0).astype(np.float64)
+    dz1 = d * (dz2.astype(np.float64) @ W2.astype(np.float64))
+    ref_dx, ref_dW, ref_db = dz1 @ W1.astype(np.float64), dz1.T @ x.astype(np.float64), dz1.sum(0)
+
+    dx = torch.full((n, n_in), 7.0, device=DEV)
+    call("mlp_bwd_input", T(dz2), n_out, T(W2), H, T(hidden), H, act1, T(W1), n_in, n, n_in, H, n_out, dx, n_in, 0)
+    close(N(dx), ref_dx, 2e-5, 2e-5 * np.abs(ref_dx).max())
+    call("mlp_bwd_input", T(dz2), n_out, T(W2), H, T(hidden), H, act1, T(W1), n_in, n, n_in, H, n_out, dx, n_in, 1)
+    close(N(dx), 2 * ref_dx, 2e-5, 4e-5 * np.abs(ref_dx).max())      # accumulate
+    dW = torch.zeros(H, n_in, device=DEV)
+    db = torch.zeros(H, device=DEV)
+    call("mlp_bwd_weight", T(dz2), n_out, T(W2), H, T(hidden), H, act1, T(x), n_in, n, n_in, H, n_out, dW, n_in, db)
+    close(N(dW), ref_dW, 2e-5, 2e-5 * np.abs(ref_dW).max())
+    close(N(db), ref_db, 2e-5, 2e-5 * np.abs(ref_db).max())
+    # a column window of W1 / x (the trainer passes rgb_net's grid-feature columns only)
+    if n_in >= 64:
+        dxw = torch.empty(n, 32, device=DEV)
+        call("mlp_bwd_input", T(dz2), n_out, T(W2), H, T(hidden), H, act1, T(W1)[:, 16:], n_in, n, 32, H, n_out,
+             dxw, 32, 0)
+        close(N(dxw), ref_dx[:, 16:48], 2e-5, 2e-5 * np.abs(ref_dx).max())
+
+
 # ---------------------------------------------------------------------------- NGP field (fused node)
 def _make_model(ngp, embed_a=False, table_scale=0.3, scale=0.5):
     torch.manual_seed(5)
