@@ -4,6 +4,7 @@ the run (steps are delimited by sumsq_kernel launches) and prints every kernel w
 duration, queue and the idle gap on the device before it.  Also prints the busy/idle split of the step.
 
 usage: timeline.py <kernel_trace.csv> [steps_from_end=3]
+       timeline.py <kernel_trace.csv> region <K>     per-kernel time over the last K steps (bench.py's timed region)
 """
 import csv
 import re
@@ -46,5 +47,30 @@ def main(path, back=3):
     print(f"# device idle inside the step: {idle/1e3:.1f} us of {wall/1e3:.1f} us")
 
 
+def region(path, k):
+    rows = []
+    for r in csv.DictReader(open(path)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    marks = [i for i, r in enumerate(rows) if "sumsq_kernel" in r[2]]
+    # the timed region ends with the optimizer of its last step: take the K steps before the last sumsq
+    lo, hi = marks[-k - 1], marks[-1]
+    sel = rows[lo:hi]
+    wall = rows[hi][0] - rows[lo][0]
+    agg = {}
+    for s, e, n in sel:
+        a = agg.setdefault(short(n), [0, 0])
+        a[0] += e - s
+        a[1] += 1
+    tot = sum(a[0] for a in agg.values())
+    print(f"# timed region only (last {k} steps): wall {wall/k/1e6:.3f} ms/step, sum of kernel durations "
+          f"{tot/k/1e6:.3f} ms/step (streams overlap), {len(sel)/k:.0f} launches/step")
+    for name, (ns, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:24]:
+        print(f"{name:60s} {ns/k/1e6:8.3f} ms/step {c/k:6.1f} calls/step {ns/c/1e3:9.1f} us/call")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+    if len(sys.argv) > 3 and sys.argv[2] == "region":
+        region(sys.argv[1], int(sys.argv[3]))
+    else:
+        main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3)
