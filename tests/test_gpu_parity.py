@@ -472,6 +472,24 @@ def test_adam_matches_torch(ngp):
     close(N(p), N(p_ref), 1e-5, 1e-6)
 
 
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 100003, 4_000_001])
+def test_sumsq_and_clip_coef(ngp, n):
+    """global gradient norm + clip coefficient (torch.nn.utils.clip_grad_norm_ semantics), aligned and
+    unaligned buffers, ragged tails"""
+    torch.manual_seed(n)
+    buf = torch.randn(n + 1, device=DEV)
+    for x in (buf[:n], buf[1:]):                       # 16-byte aligned / misaligned start
+        out = torch.zeros(2, device=DEV)
+        ngp._lib.call("sumsq", x, n, out[0:1])
+        ref = float((x.double() ** 2).sum())
+        assert abs(float(out[0]) - ref) <= 1e-5 * ref + 1e-12
+        for max_norm, extra in ((50.0, 1.0), (0.5 * ref ** 0.5, 1.0), (0.5 * ref ** 0.5, 0.125)):
+            ngp._lib.call("clip_coef", out[0:1], float(max_norm), float(extra), out[1:2])
+            norm = ref ** 0.5 * extra
+            want = extra * min(1.0, max_norm / (norm + 1e-6))
+            assert abs(float(out[1]) - want) <= 1e-5 * want
+
+
 @pytest.mark.parametrize("case", [
     # n, H, n_in, n_out, act1
     (1000, 128, 128, 1, 3),     # density head: softplus hidden, one output
