@@ -5,6 +5,9 @@ Bars: bit-exact for integer/index work and for the fp32 marcher/intersector (sam
 order, no FMA contraction on either side); stated tolerances for compositing (parallel scans,
 __expf), the hash grid (atomic summation order) and the MLP (MFMA accumulation order).
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -15,6 +18,7 @@ from helpers import borderline_rays, make_bitfield, make_rays, make_segments, rn
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def T(a):
@@ -816,6 +820,27 @@ def test_dense_render_matches_nocuda_path_psnr(ngp):
         assert psnr(rgb_gpu, rgb_cpu) > 60, (S, psnr(rgb_gpu, rgb_cpu))
         close(N(gpu["opacity"])[hit], cpu["opacity0"][hit], 1e-3, 1e-4)
         close(N(gpu["depth"])[hit], cpu["depth0"][hit], 1e-3, 1e-3)
+
+
+def test_train_from_dataset_directory(ngp, tmp_path):
+    """NeRF-Synthetic directory -> loader -> the reference's schedule -> test
+    split PSNR, end to end (the scene is the analytic proxy exported in Blender format; the
+    renderer adds a black background for synthetic scenes, so the export is RGB on black)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train_dataset as td
+    from ngp_amd.datasets import NeRFDataset, write_synthetic_dataset
+    from ngp_amd.synthetic import LegoProxy
+    scene = LegoProxy(n_images=26, img_wh=(80, 80), device=DEV)              # int(800 * 0.1)
+    root = write_synthetic_dataset(str(tmp_path), scene, n_train=24, n_test=2, rgba=False, n_quad=128)
+    train_set = NeRFDataset(root, "train", 0.1, device=DEV)
+    test_set = NeRFDataset(root, "test", 0.1, device=DEV)
+    assert train_set.rays.is_cuda and train_set.rays.shape == (24, 6400, 3)
+    torch.manual_seed(41)
+    model = td.build_model(0.5, DEV)
+    tr = td.train(model, train_set, num_epochs=2, steps_per_epoch=200, batch_size=2048, lr=1e-2)
+    assert tr.global_step == 400
+    psnrs = td.evaluate(model, test_set)
+    assert len(psnrs) == 2 and min(psnrs) > 22.0, psnrs
 
 
 def test_differentiable_normals_h4(ngp):
