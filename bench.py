@@ -183,7 +183,7 @@ def main():
         dist.barrier()
     _lib.PROFILE = {k: [] for k in ("grid_fwd", "grid_bwd_param", "grid_bwd_input", "adam_step",
                                     "linear_fwd", "linear_bwd_input", "linear_bwd_weight",
-                                    "mlp_bwd_input", "mlp_bwd_weight")}
+                                    "mlp_bwd_input", "mlp_bwd_weight", "mlp2_fwd")}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tot_samples, last = run(args.steps, args.warmup, False)
@@ -216,11 +216,11 @@ def main():
                 gbs = [BYTES_PER_SAMPLE[name] * n / (m * 1e-3) / 1e9 for n, m in zip(ns, ms) if m > 0]
                 kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
                               "avg_samples": sum(ns) / len(ns), "GBps": sum(gbs) / max(len(gbs), 1)}
-            elif name.startswith("linear") or name.startswith("mlp_bwd"):
+            elif name.startswith("linear") or name.startswith("mlp"):
                 # (.., n, n_in, n_out, ..) are int arguments 2,3,4 of the three linear_* entry points and
-                # (n, n_in, H) arguments 5,6,7 of the fused first-layer products; only the MFMA-tiled
+                # (n, n_in, H) arguments 5,6,7 of the fused 2-layer entry points (mlp2_fwd, mlp_bwd_*); only the MFMA-tiled
                 # launches count (the 1..16-wide heads run on the VALU "skinny" kernels)
-                i0 = 5 if name.startswith("mlp_bwd") else 2
+                i0 = 5 if name.startswith("mlp") else 2
                 sel = [(m, 2.0 * a[i0] * a[i0 + 1] * a[i0 + 2]) for m, (_, _, a) in zip(ms, evs)
                        if min(a[i0 + 1], a[i0 + 2]) >= 32 and m > 0]
                 if sel:
@@ -252,14 +252,14 @@ def main():
                     if dom == "grid_bwd_param" else "",
         }
         # MFMA utilisation of the MLP products against the dense f32 MFMA peak of gfx950
-        lin = [kern[k] for k in kern if k.startswith("linear") or k.startswith("mlp_bwd")]
+        lin = [kern[k] for k in kern if k.startswith("linear") or k.startswith("mlp")]
         mlp = None
         if lin:
             fl = sum(k["TFLOPs"] * k["total_ms"] for k in lin)
             t_ms = sum(k["total_ms"] for k in lin)
             mlp = {"bound": "mfma", "achieved": fl / t_ms, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": fl / t_ms / MFMA_F32_PEAK_TFLOPS, "ms_per_step": t_ms / args.steps,
-                   "note": "all MFMA-tiled linear_fwd / linear_bwd_* / mlp_bwd_* launches of the step, fp32 operands, "
+                   "note": "all MFMA-tiled linear_* / mlp2_fwd / mlp_bwd_* launches of the step, fp32 operands, "
                            "v_mfma_f32_32x32x2_f32"}
         out = {
             "metric": "train rays/sec", "value": rays_total / elapsed, "unit": "rays/s",

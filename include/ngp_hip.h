@@ -305,6 +305,14 @@ int ngp_linear_fwd(const float* x, int64_t ldx, const float* W, int64_t ldw, con
                    float* y, int64_t ldy, float* z_pre /* optional (n,n_out) pre-activation, may be NULL */,
                    void* stream);
 
+/* Forward of a 2-layer MLP in one launch: hidden (n, H<=128) = act1(x W1^T + b1) is stored (the
+ * backward needs it), out (n, n_out<=4) = act2(hidden W2^T + b2) is formed from the activated tile
+ * in the MFMA kernel's epilogue — xyz_net (networks.py:54-59), rgb_net (89-100), norm_pred_header
+ * (102-111).  b1 / b2 may be NULL (tcnn networks have no biases). */
+int ngp_mlp2_fwd(const float* x, int64_t ldx, const float* W1, int64_t ldw1, const float* b1, int act1,
+                 const float* W2, int64_t ldw2, const float* b2, int act2, int64_t n, int n_in, int H,
+                 int n_out, float* hidden, int64_t ldh, float* out, int64_t ldo, void* stream);
+
 int ngp_linear_bwd_input(const float* dz, int64_t lddz, const float* W, int64_t ldw,
                          int64_t n, int n_in, int n_out, float* dx, int64_t lddx,
                          int accumulate /* dx += instead of dx = */, void* stream);

@@ -34,6 +34,9 @@ struct GemmArgs {
     // XF kernels (DGRAD / WGRAD of the FIRST layer of a 2-layer MLP): A points at the saved hidden
     // activations and the operand dz1 = act1'(hidden) * (dz2 . W2) is formed while the tile is
     // staged, so dz1 never exists in HBM.  dz2 (rows, xf_nout) already carries act2'.
+    // F2 kernels (FWD of a 2-layer MLP whose hidden width fits one column tile): the 1..4-wide second
+    // layer out = act2(hidden . W2^T + b2) is applied to the activated tile in the epilogue
+    const float* f2_W2; int64_t f2_ldw2; const float* f2_b2; float* f2_out; int64_t f2_ldo; int f2_nout, f2_act;
     const float* xf_dz2; int64_t xf_lddz2;
     const float* xf_W2; int64_t xf_ldw2;
     int xf_nout, xf_act;
@@ -253,10 +256,11 @@ struct TileD {
 template <bool TRANSPOSED, int EXT> struct TileSel { typedef TileT<EXT> type; };
 template <int EXT> struct TileSel<false, EXT> { typedef TileD<EXT> type; };
 
-template <int MODE, int WM, int WN, int TM, int TN, int XF>   // XF = width of the fused second layer (0: plain)
+template <int MODE, int WM, int WN, int TM, int TN, int XF, int F2 = 0>   // XF / F2 = width of the fused second layer (0: plain)
 __device__ __forceinline__ void gemm_body(const GemmArgs& p)
 {
     static_assert(!XF || MODE != MODE_FWD, "the operand transform exists for DGRAD / WGRAD only");
+    static_assert(!F2 || MODE == MODE_FWD, "the second-layer epilogue exists for FWD only");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int LDA = BM + 2, LDB = BN + 2;
     __shared__ float As[BK * LDA];
@@ -321,6 +325,70 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p)
     }
     if (want_db && threadIdx.x < BM && m0 + threadIdx.x < p.M) atomicAdd(p.bias_grad + m0 + threadIdx.x, bias_acc);
 
+    if (F2) {
+        // hidden tile: bias + activation + store as usual; second layer: every lane forms the partial
+        // dot products of its TN columns for its 16 rows, a transposing butterfly over the 32 lanes
+        // of the half-wave (16 shuffles per output instead of 16 x 5) leaves one row total per
+        // lane pair, the WN column halves meet in LDS (the staging tiles are free by now).
+        float* red = As;   // [WN][BM][F2]
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) {
+            float part[F2 ? F2 : 1][16];
+#pragma unroll
+            for (int o = 0; o < F2; o++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) part[o][r] = 0.0f;
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) {
+                const int64_t n = n0 + (wn * TN + tn) * 32 + li;
+                const bool ncol = n < p.N;
+                const float bv = (ncol && p.bias) ? p.bias[n] : 0.0f;
+                float w2[F2 ? F2 : 1];
+#pragma unroll
+                for (int o = 0; o < F2; o++) w2[o] = (ncol && o < p.f2_nout) ? p.f2_W2[o * p.f2_ldw2 + n] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float v = act_fwd(acc[tm][tn][r] + bv, p.act);
+                    if (ncol && m < p.M) p.C[m * p.ldc + n] = v;
+#pragma unroll
+                    for (int o = 0; o < F2; o++) part[o][r] = fmaf(v, w2[o], part[o][r]);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < F2; o++) {
+                float* v = part[o];
+#pragma unroll
+                for (int half = 8; half >= 1; half >>= 1) {
+                    const int mask = half * 2;   // 16, 8, 4, 2
+                    const bool up = (li & mask) != 0;
+#pragma unroll
+                    for (int j = 0; j < half; j++) {
+                        const float keep = up ? v[j + half] : v[j];
+                        const float send = up ? v[j] : v[j + half];
+                        v[j] = keep + __shfl_xor(send, mask, 64);
+                    }
+                }
+                const float tot = v[0] + __shfl_xor(v[0], 1, 64);
+                const int rr = ((li >> 4) & 1) * 8 + ((li >> 3) & 1) * 4 + ((li >> 2) & 1) * 2 + ((li >> 1) & 1);
+                const int row = (wm * TM + tm) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                if ((li & 1) == 0) red[(wn * BM + row) * F2 + o] = tot;
+            }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < BM * F2; idx += 256) {
+            const int row = idx / F2, o = idx - row * F2;
+            const int64_t m = m0 + row;
+            if (o < p.f2_nout && m < p.M) {
+                float sum = p.f2_b2 ? p.f2_b2[o] : 0.0f;
+#pragma unroll
+                for (int w = 0; w < WN; w++) sum += red[(w * BM + row) * F2 + o];
+                p.f2_out[m * p.f2_ldo + o] = act_fwd(sum, p.f2_act);
+            }
+        }
+        return;
+    }
+
 #pragma unroll
     for (int tm = 0; tm < TM; tm++)
 #pragma unroll
@@ -351,6 +419,13 @@ template <int MODE, int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs p)
 {
     gemm_body<MODE, WM, WN, TM, TN, 0>(p);
+}
+
+// 2-layer forward: hidden = act1(x W1^T + b1) stored, out = act2(hidden W2^T + b2) from the epilogue
+template <int WM, int WN, int TM, int TN, int F2>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) gemm_fwd2_kernel(GemmArgs p)
+{
+    gemm_body<MODE_FWD, WM, WN, TM, TN, 0, F2>(p);
 }
 
 // operand-transform variant: the extra staging registers must not cost the third workgroup per CU
@@ -796,6 +871,32 @@ int ngp_linear_fwd(const float* x, int64_t ldx, const float* W, int64_t ldw, con
     } else {
         dim3 grid(ngp_blocks(n, 128), 1);
         hipLaunchKernelGGL((gemm_kernel<MODE_FWD, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+    }
+    return ngp_check_launch();
+}
+
+int ngp_mlp2_fwd(const float* x, int64_t ldx, const float* W1, int64_t ldw1, const float* b1, int act1,
+                 const float* W2, int64_t ldw2, const float* b2, int act2, int64_t n, int n_in, int H, int n_out,
+                 float* hidden, int64_t ldh, float* out, int64_t ldo, void* stream)
+{
+    if (n < 0 || n_in < 1 || H < 1 || H > 128 || n_out < 1 || n_out > 4 || ldx < n_in || ldw1 < n_in || ldh < H ||
+        ldw2 < H || ldo < n_out)
+        return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!x || !W1 || !W2 || !hidden || !out) return NGP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs p{};
+    p.A = x; p.lda = ldx; p.B = W1; p.ldb = ldw1; p.C = hidden; p.ldc = ldh;
+    p.M = n; p.N = H; p.K = n_in; p.bias = b1; p.act = act1;
+    p.vecA = aligned16(x) && (ldx % 4 == 0); p.vecB = aligned16(W1) && (ldw1 % 4 == 0);
+    p.f2_W2 = W2; p.f2_ldw2 = ldw2; p.f2_b2 = b2; p.f2_out = out; p.f2_ldo = ldo; p.f2_nout = n_out; p.f2_act = act2;
+    dim3 grid(ngp_blocks(n, 128), 1);
+    if (H > 32) {
+        if (n_out == 1) hipLaunchKernelGGL((gemm_fwd2_kernel<2, 2, 2, 2, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_fwd2_kernel<2, 2, 2, 2, 4>), grid, dim3(256), 0, st, p);
+    } else {
+        if (n_out == 1) hipLaunchKernelGGL((gemm_fwd2_kernel<4, 1, 1, 1, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_fwd2_kernel<4, 1, 1, 1, 4>), grid, dim3(256), 0, st, p);
     }
     return ngp_check_launch();
 }

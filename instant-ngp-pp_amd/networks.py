@@ -75,6 +75,7 @@ _RELU, _NONE = 1, 0
 import os as _os
 
 _OVERLAP = _os.environ.get("NGP_NO_OVERLAP", "0") != "1"
+_FUSED_FWD = _os.environ.get("NGP_NO_FUSED_FWD", "0") != "1"   # A/B switch for ngp_mlp2_fwd
 _FUSED_BWD = _os.environ.get("NGP_NO_FUSED_BWD", "0") != "1"   # A/B switch for the operand-transform products
 # widest second layer that takes the fused route: measured on MI355X (tools/mlp_bwd_microbench.py,
 # n = 433 k) the density head (1 output) gains 16 % (0.53 -> 0.45 ms), 3 outputs lose 6 % (the
@@ -208,9 +209,12 @@ class _FieldFn(Function):
         feat = torch.empty(n, 128, dtype=_f32, device=dev)
         call("grid_fwd", xe.desc, xyz_table, xn, n, feat, 128)
         a1 = torch.empty(n, 128, dtype=_f32, device=dev)
-        call("linear_fwd", feat, 128, W1, 128, b1, n, 128, 128, _SOFTPLUS, a1, 128, None)
         sig = torch.empty(n, 1, dtype=_f32, device=dev)
-        call("linear_fwd", a1, 128, W2, 128, b2, n, 128, 1, _SOFTPLUS, sig, 1, None)
+        if _FUSED_FWD:   # both layers in one launch: the 1-wide second layer rides in the MFMA epilogue
+            call("mlp2_fwd", feat, 128, W1, 128, b1, _SOFTPLUS, W2, 128, b2, _SOFTPLUS, n, 128, 128, 1, a1, 128, sig, 1)
+        else:
+            call("linear_fwd", feat, 128, W1, 128, b1, n, 128, 128, _SOFTPLUS, a1, 128, None)
+            call("linear_fwd", a1, 128, W2, 128, b2, n, 128, 1, _SOFTPLUS, sig, 1, None)
         # analytic d(sigma)/dx: back-substitute ones through the head, then the grid input gradient
         dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
         if _FUSED_BWD:
@@ -238,13 +242,19 @@ class _FieldFn(Function):
         feat_rgb = rgb_in[:, 16:144]
         net = model.rgb_net
         a_r = torch.empty(n, 128, dtype=_f32, device=dev)
-        call("linear_fwd", rgb_in, Kp, rgb_p, Kp, None, n, Kp, 128, _RELU, a_r, 128, None)
         rgb_o = torch.empty(n, 3, dtype=_f32, device=dev)
-        call("linear_fwd", a_r, 128, rgb_p[128 * Kp:], 128, None, n, 128, 3, net.output_activation, rgb_o, 3, None)
         a_n = torch.empty(n, 32, dtype=_f32, device=dev)
-        call("linear_fwd", feat_rgb, Kp, nrm_p, 128, None, n, 128, 32, _RELU, a_n, 32, None)
         np_o = torch.empty(n, 3, dtype=_f32, device=dev)
-        call("linear_fwd", a_n, 32, nrm_p[32 * 128:], 32, None, n, 32, 3, _NONE, np_o, 3, None)
+        if _FUSED_FWD:
+            call("mlp2_fwd", rgb_in, Kp, rgb_p, Kp, None, _RELU, rgb_p[128 * Kp:], 128, None, net.output_activation,
+                 n, Kp, 128, 3, a_r, 128, rgb_o, 3)
+            call("mlp2_fwd", feat_rgb, Kp, nrm_p, 128, None, _RELU, nrm_p[32 * 128:], 32, None, _NONE,
+                 n, 128, 32, 3, a_n, 32, np_o, 3)
+        else:
+            call("linear_fwd", rgb_in, Kp, rgb_p, Kp, None, n, Kp, 128, _RELU, a_r, 128, None)
+            call("linear_fwd", a_r, 128, rgb_p[128 * Kp:], 128, None, n, 128, 3, net.output_activation, rgb_o, 3, None)
+            call("linear_fwd", feat_rgb, Kp, nrm_p, 128, None, n, 128, 32, _RELU, a_n, 32, None)
+            call("linear_fwd", a_n, 32, nrm_p[32 * 128:], 32, None, n, 32, 3, _NONE, np_o, 3, None)
         a_s = torch.empty(n, 32, dtype=_f32, device=dev)
         call("linear_fwd", feat_rgb, Kp, sem_p, 128, None, n, 128, 32, _RELU, a_s, 32, None)
         sem_o = torch.empty(n, C, dtype=_f32, device=dev)
@@ -449,9 +459,9 @@ class NGP(nn.Module):
                 feat = torch.empty(n, 128, dtype=_f32, device=x.device)
                 call("grid_fwd", self.xyz_encoder.desc, self.xyz_encoder.params, x, n, feat, 128)
                 a1 = torch.empty(n, 128, dtype=_f32, device=x.device)
-                call("linear_fwd", feat, 128, lin1.weight, 128, lin1.bias, n, 128, 128, _SOFTPLUS, a1, 128, None)
                 sig = torch.empty(n, 1, dtype=_f32, device=x.device)
-                call("linear_fwd", a1, 128, lin2.weight, 128, lin2.bias, n, 128, 1, _SOFTPLUS, sig, 1, None)
+                call("mlp2_fwd", feat, 128, lin1.weight, 128, lin1.bias, _SOFTPLUS, lin2.weight, 128, lin2.bias,
+                     _SOFTPLUS, n, 128, 128, 1, a1, 128, sig, 1)
                 sigmas = sig[:, 0]
         else:
             sigmas = self._density_head(self.xyz_encoder(x))

@@ -476,6 +476,47 @@ def test_adam_matches_torch(ngp):
     close(N(p), N(p_ref), 1e-5, 1e-6)
 
 
+@pytest.mark.parametrize("case", [
+    # n, n_in, H, n_out, act1, act2, biases
+    (1000, 128, 128, 1, 3, 3, True),     # xyz_net: softplus / softplus with biases
+    (1531, 160, 128, 3, 1, 2, False),    # rgb_net with appearance codes: ReLU / sigmoid
+    (777, 128, 32, 3, 1, 0, False),      # norm_pred_header
+    (130, 144, 128, 4, 1, 0, False),     # 4 outputs, two row tiles, second one ragged
+    (5, 16, 64, 2, 1, 4, True),          # H = 64 (half-empty column tile), exp output
+])
+def test_mlp2_fwd_fused(ngp, case):
+    """ngp_mlp2_fwd (second layer applied in the MFMA kernel's epilogue) against fp64"""
+    from ngp_amd._lib import call
+    n, n_in, H, n_out, act1, act2, biases = case
+    g = rng(320 + n)
+    x = g.normal(size=(n, n_in)).astype(np.float32)
+    W1 = (g.normal(size=(H, n_in)) / np.sqrt(n_in)).astype(np.float32)
+    W2 = (g.normal(size=(n_out, H)) / np.sqrt(H)).astype(np.float32)
+    b1 = g.normal(size=H).astype(np.float32) if biases else None
+    b2 = g.normal(size=n_out).astype(np.float32) if biases else None
+
+    def act(v, a):
+        return {0: v, 1: np.maximum(v, 0), 2: 1 / (1 + np.exp(-v)), 3: np.logaddexp(0, v), 4: np.exp(v)}[a]
+    z1 = x.astype(np.float64) @ W1.astype(np.float64).T + (0 if b1 is None else b1)
+    h_ref = act(z1, act1)
+    o_ref = act(h_ref @ W2.astype(np.float64).T + (0 if b2 is None else b2), act2)
+    hidden = torch.full((n, H), 9.0, device=DEV)
+    out = torch.full((n, n_out), 9.0, device=DEV)
+    call("mlp2_fwd", T(x), n_in, T(W1), n_in, None if b1 is None else T(b1), act1, T(W2), H,
+         None if b2 is None else T(b2), act2, n, n_in, H, n_out, hidden, H, out, n_out)
+    close(N(hidden), h_ref, 2e-5, 2e-5)
+    close(N(out), o_ref, 3e-5, 3e-5)
+    # strided operands: input taken from a wider matrix, hidden written into a wider one
+    wide = torch.zeros(n, n_in + 16, device=DEV)
+    wide[:, 16:] = T(x)
+    hid_w = torch.zeros(n, H + 8, device=DEV)
+    call("mlp2_fwd", wide[:, 16:], n_in + 16, T(W1), n_in, None if b1 is None else T(b1), act1, T(W2), H,
+         None if b2 is None else T(b2), act2, n, n_in, H, n_out, hid_w, H + 8, out, n_out)
+    close(N(hid_w[:, :H]), h_ref, 2e-5, 2e-5)
+    assert not hid_w[:, H:].any()
+    close(N(out), o_ref, 3e-5, 3e-5)
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 1023, 100003, 4_000_001])
 def test_sumsq_and_clip_coef(ngp, n):
     """global gradient norm + clip coefficient (torch.nn.utils.clip_grad_norm_ semantics), aligned and
