@@ -416,7 +416,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p)
 }
 
 template <int MODE, int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs p)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) gemm_kernel(GemmArgs p)
 {
     gemm_body<MODE, WM, WN, TM, TN, 0>(p);
 }
