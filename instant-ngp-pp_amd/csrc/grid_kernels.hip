@@ -314,6 +314,108 @@ __global__ void __launch_bounds__(256) grid_bwd_param_merge2_kernel(GridMeta met
     if (have) flush();
 }
 
+// merge2 with corner-level carry-over.  The run-merging kernels above flush all corners whenever
+// the CELL changes; but a sample that moves to a neighbouring cell keeps half (face move), a
+// quarter (edge move) or one (diagonal move) of its eight corners.  Here every lane keeps its four
+// (y,z) accumulators addressed relative to a sliding 2x2x2 window: on a move of at most one cell
+// per axis only the corners that LEAVE the window are flushed, the others slide to their new slot
+// (y/z moves: inside the lane; x moves: between the two x-corner lanes of the level, lane ^ F).
+// Each visited corner is then flushed once per visit — the fewest atomics run merging can issue.
+template <int F, int CHUNK>
+__global__ void __launch_bounds__(256) grid_bwd_param_slide_kernel(GridMeta meta, const float* __restrict__ x,
+                                                                   const float* __restrict__ dL_dy, int64_t lddy,
+                                                                   int64_t n, float* __restrict__ dtable)
+{
+    constexpr int LV = 64 / (2 * F);  // levels per wave
+    constexpr int SUB = 8;
+    const uint32_t L = meta.n_levels;
+    const uint32_t waves_per_chunk = (L + LV - 1) / LV;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t chunk = __builtin_amdgcn_readfirstlane((int)(wave_global / waves_per_chunk));
+    const uint32_t lg = __builtin_amdgcn_readfirstlane((int)(wave_global % waves_per_chunk));
+    const int lane = threadIdx.x & 63;
+    const uint32_t level = lg * LV + lane / (2 * F);
+    const uint32_t xb = (lane / F) & 1;
+    const int f = lane % F;
+    const int64_t s0 = chunk * CHUNK;
+    if (s0 >= n) return;
+    const int64_t s1 = s0 + CHUNK < n ? s0 + CHUNK : n;
+    const bool active = level < L;
+    const LevelInfo li = level_info(meta, active ? level : 0);
+    const size_t ld = (size_t)lddy;
+
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;   // slots (cy,cz) = (0,0) (1,0) (0,1) (1,1)
+    int b0 = 0, b1 = 0, b2 = 0;
+    bool have = false;
+
+    auto put = [&](float& a, int gx, int gy, int gz) {
+        if (a != 0.0f) {
+            const uint32_t row = row_index(li, (uint32_t)gx, (uint32_t)gy, (uint32_t)gz);
+            atomicAdd(dtable + (size_t)row * F + f, a);
+        }
+        a = 0.0f;
+    };
+
+    for (int64_t sb = s0; sb < s1; sb += SUB) {
+        float g[SUB], px[SUB], py[SUB], pz[SUB];
+#pragma unroll
+        for (int j = 0; j < SUB; j++) {
+            const int64_t s = sb + j < s1 ? sb + j : s1 - 1;
+            g[j] = active ? dL_dy[(size_t)s * ld + level * F + f] : 0.0f;
+            px[j] = x[3 * s]; py[j] = x[3 * s + 1]; pz[j] = x[3 * s + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < SUB; j++) {
+            if (sb + j >= s1) break;
+            const float p0 = fmaf(li.scale, px[j], 0.5f), p1 = fmaf(li.scale, py[j], 0.5f), p2 = fmaf(li.scale, pz[j], 0.5f);
+            const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+            const int g0 = (int)f0, g1 = (int)f1, g2 = (int)f2;
+            const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+            const int dx = g0 - b0, dy = g1 - b1, dz = g2 - b2;
+            if (have && (dx | dy | dz) != 0) {
+                const int X = b0 + (int)xb;
+                const bool near_move = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+                if (!near_move) {
+                    put(a0, X, b1, b2); put(a1, X, b1 + 1, b2); put(a2, X, b1, b2 + 1); put(a3, X, b1 + 1, b2 + 1);
+                } else {
+                    // corners leaving the window in y / z
+                    const bool fy0 = dy == 1, fy1 = dy == -1, fz0 = dz == 1, fz1 = dz == -1;
+                    if (fy0 || fz0) put(a0, X, b1, b2);
+                    if (fy1 || fz0) put(a1, X, b1 + 1, b2);
+                    if (fy0 || fz1) put(a2, X, b1, b2 + 1);
+                    if (fy1 || fz1) put(a3, X, b1 + 1, b2 + 1);
+                    // slide the survivors (flushed slots are zero)
+                    if (dy == 1) { a0 = a1; a1 = 0.0f; a2 = a3; a3 = 0.0f; }
+                    else if (dy == -1) { a1 = a0; a0 = 0.0f; a3 = a2; a2 = 0.0f; }
+                    if (dz == 1) { a0 = a2; a2 = 0.0f; a1 = a3; a3 = 0.0f; }
+                    else if (dz == -1) { a2 = a0; a0 = 0.0f; a3 = a1; a1 = 0.0f; }
+                    if (dx != 0) {
+                        // the x-corner that stays in the window changes lanes: the lane whose old X
+                        // leaves flushes (at the NEW y/z base), then takes over its partner's sums
+                        const bool leaving = (dx == 1) ? (xb == 0) : (xb == 1);
+                        if (leaving) {
+                            put(a0, X, g1, g2); put(a1, X, g1 + 1, g2); put(a2, X, g1, g2 + 1); put(a3, X, g1 + 1, g2 + 1);
+                        }
+                        const float q0 = __shfl_xor(a0, F, 64), q1 = __shfl_xor(a1, F, 64);
+                        const float q2 = __shfl_xor(a2, F, 64), q3 = __shfl_xor(a3, F, 64);
+                        if (leaving) { a0 = q0; a1 = q1; a2 = q2; a3 = q3; }
+                        else { a0 = 0.0f; a1 = 0.0f; a2 = 0.0f; a3 = 0.0f; }
+                    }
+                }
+            }
+            b0 = g0; b1 = g1; b2 = g2; have = true;
+            const float xw = (xb ? w0 : 1 - w0) * g[j];
+            const float y0 = 1 - w1, y1 = w1, z0 = 1 - w2, z1 = w2;
+            a0 = fmaf(xw * y0, z0, a0); a1 = fmaf(xw * y1, z0, a1);
+            a2 = fmaf(xw * y0, z1, a2); a3 = fmaf(xw * y1, z1, a3);
+        }
+    }
+    if (have) {
+        const int X = b0 + (int)xb;
+        put(a0, X, b1, b2); put(a1, X, b1 + 1, b2); put(a2, X, b1, b2 + 1); put(a3, X, b1 + 1, b2 + 1);
+    }
+}
+
 // ------------------------------------------------------------------ input gradient (H3)
 // GROUP = lanes that belong to one sample (L * LPI, a power of two <= 64): their partial
 // (dx,dy,dz) are summed with xor-shuffles and lane 0 of the group stores the result.
@@ -658,7 +760,12 @@ int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* d
         if (getenv("NGP_GRID_BWD_SIMPLE")) // one atomic per (sample, level, corner, feature): kept for A/B timing
             hipLaunchKernelGGL(grid_bwd_param_kernel<F>, dim3(ngp_blocks(n_items * F, 256)), dim3(256), 0, st, m, x,
                                dL_dy, lddy, n_items, dtable);
-        else if (F == 8 && !getenv("NGP_GRID_BWD_NOPAIR")) {
+        else if (F == 8 && !getenv("NGP_GRID_BWD_NOPAIR") && !getenv("NGP_GRID_BWD_NOSLIDE")) {
+            constexpr int LV2 = 64 / (2 * F) > 0 ? 64 / (2 * F) : 1;
+            const int64_t waves2 = ((n + CHUNK - 1) / CHUNK) * ((m.n_levels + LV2 - 1) / LV2);
+            hipLaunchKernelGGL((grid_bwd_param_slide_kernel<F, CHUNK>), dim3(ngp_blocks(waves2 * 64, 256)), dim3(256),
+                               0, st, m, x, dL_dy, lddy, n, dtable);
+        } else if (F == 8 && !getenv("NGP_GRID_BWD_NOPAIR")) {
             constexpr int LV2 = 64 / (2 * F) > 0 ? 64 / (2 * F) : 1;
             const int64_t waves2 = ((n + CHUNK - 1) / CHUNK) * ((m.n_levels + LV2 - 1) / LV2);
             // optional occupancy cap (unused dynamic LDS per block) so that a kernel on another

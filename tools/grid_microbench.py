@@ -65,9 +65,12 @@ for idx, args in enumerate(captured["grid_bwd_param"]):
     nz_rows = (dy.abs().sum(1) > 0).float().mean().item()
     nz_el = (dy != 0).float().mean().item()
     tbl = torch.zeros(desc.offsets[desc.n_levels] * desc.n_features, device=dev)
-    for variant in os.environ.get("MB_VARIANTS", "pair,merge,simple").split(","):
+    for variant in os.environ.get("MB_VARIANTS", "slide,pair,merge,simple").split(","):
         os.environ.pop("NGP_GRID_BWD_SIMPLE", None)
         os.environ.pop("NGP_GRID_BWD_NOPAIR", None)
+        os.environ.pop("NGP_GRID_BWD_NOSLIDE", None)
+        if variant == "pair":
+            os.environ["NGP_GRID_BWD_NOSLIDE"] = "1"
         if variant == "simple":
             os.environ["NGP_GRID_BWD_SIMPLE"] = "1"
         if variant == "merge":
@@ -77,6 +80,7 @@ for idx, args in enumerate(captured["grid_bwd_param"]):
               f"{variant}: {ms:.3f} ms  alg {n*4608/ms/1e6:.0f} GB/s  (nonzero-only {n*nz_rows*4608/ms/1e6:.0f} GB/s)")
     os.environ.pop("NGP_GRID_BWD_SIMPLE", None)
     os.environ.pop("NGP_GRID_BWD_NOPAIR", None)
+    os.environ.pop("NGP_GRID_BWD_NOSLIDE", None)
     # all-nonzero gradient for the same positions: the kernel's ceiling without sparsity
     dyr = torch.randn_like(dy)
     ms = timeit(lambda: orig_call("grid_bwd_param", desc, x, dyr, lddy, n, tbl))
