@@ -327,7 +327,9 @@ int ngp_act_bwd(const float* dy, const float* y, int64_t count, int activation,
 int ngp_mlp_hidden_bwd(const float* dOut, int64_t lddo, const float* out, int64_t ldo, int act2,
                        const float* W2, int64_t ldw2, const float* hidden, int64_t ldh, int act1,
                        int64_t n, int H, int n_out, float* dz2, int64_t lddz2,
-                       float* dz1, int64_t lddz1, void* stream);
+                       float* dz1, int64_t lddz1,
+                       float* dW2 /* NULL, or (n_out<=4, H): += dz2^T . hidden from the same pass */,
+                       int64_t lddw2, float* db2 /* NULL or (n_out): += column sums of dz2 */, void* stream);
 
 /* Backward of the FIRST layer of a 2-layer MLP  x -> hidden = act1(x W1^T + b1) -> out = act2(hidden W2^T + b2)
  * (n_out <= 4: xyz_net, rgb_net, norm_pred_header) with the hidden-layer gradient
@@ -336,13 +338,17 @@ int ngp_mlp_hidden_bwd(const float* dOut, int64_t lddo, const float* out, int64_
  * read from HBM (it is n x 128 floats, and the plain route ngp_mlp_hidden_bwd -> ngp_linear_bwd_*
  * moves it three times):
  *   ngp_mlp_bwd_input : dx (n, n_in) (+)= dz1 . W1[:, :n_in]
- *   ngp_mlp_bwd_weight: dW1 (H, n_in) += dz1^T . x,  db1 (H) += column sums of dz1 (db1 may be NULL) */
+ *   ngp_mlp_bwd_weight: dW1 (H, n_in) += dz1^T . x,  db1 (H) += column sums of dz1 (db1 may be NULL);
+ *                       optionally also the SECOND layer's dW2 / db2, whose operands (dz2, hidden) this
+ *                       product streams anyway */
 int ngp_mlp_bwd_input(const float* dz2, int64_t lddz2, const float* W2, int64_t ldw2, const float* hidden,
                       int64_t ldh, int act1, const float* W1, int64_t ldw1, int64_t n, int n_in, int H,
                       int n_out, float* dx, int64_t lddx, int accumulate, void* stream);
 int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t ldw2, const float* hidden,
                        int64_t ldh, int act1, const float* x, int64_t ldx, int64_t n, int n_in, int H,
-                       int n_out, float* dW1, int64_t ldw, float* db1, void* stream);
+                       int n_out, float* dW1, int64_t ldw, float* db1,
+                       float* dW2 /* NULL, or (n_out, H): += dz2^T . hidden from the same pass */,
+                       int64_t lddw2, float* db2 /* NULL or (n_out): += column sums of dz2 */, void* stream);
 
 /* ------------------------------------------------------------------------
  * fused Adam step (torch.optim.Adam(eps=1e-8) semantics, train.py:244) over one

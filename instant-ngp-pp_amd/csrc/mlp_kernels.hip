@@ -40,6 +40,7 @@ struct GemmArgs {
     const float* xf_dz2; int64_t xf_lddz2;
     const float* xf_W2; int64_t xf_ldw2;
     int xf_nout, xf_act;
+    float* xf_dW2; int64_t xf_lddw2; float* xf_db2;   // XF WGRAD: also dW2 += dz2^T . hidden, db2 += colsum(dz2)
 };
 
 // softplus(v) = log(1+e^v) with the hardware exp/log (v_exp_f32 / v_log_f32, ~1e-6 relative):
@@ -153,6 +154,8 @@ struct TileT {
             for (int j = 0; j < 4; j++) v[pass][j] = s[j] * act_grad_fast(v[pass][j], act);
         }
     }
+    template <int OM>
+    __device__ __forceinline__ void w2_accumulate(float (&)[XF_OMAX][4], float (&)[XF_OMAX]) const {}
     // dst[k][row], k-major with leading dimension LD
     template <int LD>
     __device__ __forceinline__ void commit(float* __restrict__ dst) const
@@ -237,6 +240,20 @@ struct TileD {
             for (int j = 0; j < 4; j++) v[pass][j] = s[j] * act_grad_fast(v[pass][j], act);
         }
     }
+    // second-layer weight gradient from the tile that is in registers anyway (raw hidden, before
+    // xform): gw[o][j] += dz2[k][o] * hidden[k][col+j]; gb[o] += dz2[k][o] (zero rows are zero)
+    template <int OM>
+    __device__ __forceinline__ void w2_accumulate(float (&gw)[XF_OMAX][4], float (&gb)[XF_OMAX]) const
+    {
+#pragma unroll
+        for (int pass = 0; pass < PASSES; pass++)
+#pragma unroll
+            for (int o = 0; o < OM; o++) {
+                gb[o] += d2[pass][o];
+#pragma unroll
+                for (int j = 0; j < 4; j++) gw[o][j] = fmaf(d2[pass][o], v[pass][j], gw[o][j]);
+            }
+    }
     template <int LD>
     __device__ __forceinline__ void commit(float* __restrict__ dst) const
     {
@@ -290,11 +307,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p)
     typename TileSel<MODE == MODE_FWD, BN>::type tb;
     float bias_acc = 0.0f; // WGRAD: column sums of dz for db (blockIdx.y == 0 only)
     const bool want_db = MODE == MODE_WGRAD && p.bias_grad != nullptr && blockIdx.y == 0;
+    const bool want_w2 = XF != 0 && MODE == MODE_WGRAD && p.xf_dW2 != nullptr && blockIdx.y == 0;
+    float gw2[XF_OMAX][4], gb2[XF_OMAX];
+#pragma unroll
+    for (int o = 0; o < XF_OMAX; o++) {
+        gb2[o] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) gw2[o][j] = 0.0f;
+    }
 
     ta.fetch(p.A, p.lda, m0, p.M, kbeg, kend, p.vecA);
     if (XF) ta.template xf_fetch<XF>(p, m0, p.M, kbeg, kend);
     tb.fetch(p.B, p.ldb, n0, p.N, kbeg, kend, p.vecB);
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        if (XF && MODE == MODE_WGRAD && want_w2) ta.template w2_accumulate<XF>(gw2, gb2);
         if (XF) ta.template xform<XF>(p.xf_act);   // hidden -> dz1 in registers, on its way to LDS
         ta.template commit<LDA>(As);
         tb.template commit<LDB>(Bs);
@@ -324,6 +350,40 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p)
         __syncthreads();
     }
     if (want_db && threadIdx.x < BM && m0 + threadIdx.x < p.M) atomicAdd(p.bias_grad + m0 + threadIdx.x, bias_acc);
+    if (XF != 0 && MODE == MODE_WGRAD) {
+        // dW2 / db2 partials: threads with the same column quad (t % TPR) meet in LDS (the staging
+        // tiles are free: the K loop ended with a barrier), one atomic per output element and block
+        constexpr int TPR = BM / 4;             // threads per k-row of the A tile
+        constexpr int GRP = 256 / TPR;          // k-rows per pass = partials per column
+        __shared__ float red[(XF ? XF : 1) * (1024 + 32)];   // [GRP][XF][BM] (= 1024 XF floats for every BM) + [GRP][XF]
+        if (want_w2) {
+            const int t = threadIdx.x, grp = t / TPR, c4 = (t % TPR) * 4;
+#pragma unroll
+            for (int o = 0; o < XF; o++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) red[(grp * XF + o) * BM + c4 + j] = gw2[o][j];
+                if (c4 == 0) red[GRP * XF * BM + grp * XF + o] = gb2[o];
+            }
+        }
+        __syncthreads();
+        if (want_w2) {
+            for (int idx = threadIdx.x; idx < XF * BM; idx += 256) {
+                const int o = idx / BM, c = idx - o * BM;
+                if (o < p.xf_nout && m0 + c < p.M) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int g = 0; g < GRP; g++) sum += red[(g * XF + o) * BM + c];
+                    atomicAdd(p.xf_dW2 + o * p.xf_lddw2 + m0 + c, sum);
+                }
+            }
+            if (p.xf_db2 && blockIdx.x == 0 && threadIdx.x < XF && threadIdx.x < p.xf_nout) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int g = 0; g < GRP; g++) sum += red[GRP * XF * BM + g * XF + threadIdx.x];
+                atomicAdd(p.xf_db2 + threadIdx.x, sum);
+            }
+        }
+    }
 
     if (F2) {
         // hidden tile: bias + activation + store as usual; second layer: every lane forms the partial
@@ -620,14 +680,16 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 // Thread = hidden column j, W2's column in registers, rows strided over the grid.  Replaces an
 // MFMA dgrad with K <= 16 plus two elementwise passes; purely bandwidth bound.
 // dOut == nullptr means "all ones" (the d(sigma)/dx pass of the density head).
-template <int OMAX>
+template <int OMAX, bool W2G>
 __global__ void __launch_bounds__(256) mlp_hidden_bwd_kernel(const float* __restrict__ dOut, int64_t lddo,
                                                              const float* __restrict__ out, int64_t ldo, int act2,
                                                              const float* __restrict__ W2, int64_t ldw2,
                                                              const float* __restrict__ hidden, int64_t ldh, int act1,
                                                              int64_t n, int H, int n_out,
                                                              float* __restrict__ dz2, int64_t lddz2,
-                                                             float* __restrict__ dz1, int64_t lddz1)
+                                                             float* __restrict__ dz1, int64_t lddz1,
+                                                             float* __restrict__ dW2, int64_t lddw2,
+                                                             float* __restrict__ db2)
 {
     // lane = (row lane, 4 consecutive hidden columns): 16-byte loads/stores of hidden / dz1
     const int lpr = H / 4;                 // lanes per row
@@ -635,10 +697,17 @@ __global__ void __launch_bounds__(256) mlp_hidden_bwd_kernel(const float* __rest
     const int j4 = (threadIdx.x % lpr) * 4;
     const int rsub = threadIdx.x / lpr;
     float w[OMAX][4];
+    float gw[W2G ? OMAX : 1][4], gb[W2G ? OMAX : 1];   // W2G: dW2 / db2 partials of this thread
 #pragma unroll
     for (int o = 0; o < OMAX; o++)
 #pragma unroll
         for (int c = 0; c < 4; c++) w[o][c] = o < n_out ? W2[o * ldw2 + j4 + c] : 0.0f;
+#pragma unroll
+    for (int o = 0; o < (W2G ? OMAX : 1); o++) {
+        gb[o] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) gw[o][c] = 0.0f;
+    }
     const int64_t stride = (int64_t)gridDim.x * rows_per_block;
     for (int64_t row0 = (int64_t)blockIdx.x * rows_per_block + rsub; row0 < n; row0 += 2 * stride) {
         float4 hv[2];
@@ -662,6 +731,11 @@ __global__ void __launch_bounds__(256) mlp_hidden_bwd_kernel(const float* __rest
 #pragma unroll
                     for (int c = 0; c < 4; c++) acc[u][c] = fmaf(d, w[o][c], acc[u][c]);
                     if (dz2 && j4 == 0) dz2[row * lddz2 + o] = d;
+                    if (W2G) {
+                        gb[o] += d;
+                        gw[o][0] = fmaf(d, hv[u].x, gw[o][0]); gw[o][1] = fmaf(d, hv[u].y, gw[o][1]);
+                        gw[o][2] = fmaf(d, hv[u].z, gw[o][2]); gw[o][3] = fmaf(d, hv[u].w, gw[o][3]);
+                    }
                 }
             }
         }
@@ -675,6 +749,31 @@ __global__ void __launch_bounds__(256) mlp_hidden_bwd_kernel(const float* __rest
             r.z = acc[u][2] * act_grad_from_output(hv[u].z, act1);
             r.w = acc[u][3] * act_grad_from_output(hv[u].w, act1);
             *reinterpret_cast<float4*>(dz1 + row * lddz1 + j4) = r;
+        }
+    }
+    if (W2G) {
+        // threads that own the same four columns (same threadIdx % lpr) meet in LDS; one atomic per
+        // output element and block (the launch is capped at 1024 blocks for that reason)
+        __shared__ float red[256 * 4 * OMAX + 256 * OMAX];
+#pragma unroll
+        for (int o = 0; o < OMAX; o++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) red[(rsub * OMAX + o) * H + j4 + c] = gw[o][c];   // [rsub][o][H]: 256*4*OMAX floats
+            if (j4 == 0) red[256 * 4 * OMAX + rsub * OMAX + o] = gb[o];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < OMAX * H; idx += 256) {
+            const int o = idx / H, c = idx - o * H;
+            if (o < n_out) {
+                float sum = 0.0f;
+                for (int r = 0; r < rows_per_block; r++) sum += red[(r * OMAX + o) * H + c];
+                atomicAdd(dW2 + o * lddw2 + c, sum);
+            }
+        }
+        if (db2 && threadIdx.x < OMAX && threadIdx.x < n_out) {
+            float sum = 0.0f;
+            for (int r = 0; r < rows_per_block; r++) sum += red[256 * 4 * OMAX + r * OMAX + threadIdx.x];
+            atomicAdd(db2 + threadIdx.x, sum);
         }
     }
 }
@@ -959,22 +1058,30 @@ int ngp_act_bwd(const float* dy, const float* y_or_z, int64_t count, int activat
 
 int ngp_mlp_hidden_bwd(const float* dOut, int64_t lddo, const float* out, int64_t ldo, int act2, const float* W2,
                        int64_t ldw2, const float* hidden, int64_t ldh, int act1, int64_t n, int H, int n_out,
-                       float* dz2, int64_t lddz2, float* dz1, int64_t lddz1, void* stream)
+                       float* dz2, int64_t lddz2, float* dz1, int64_t lddz1, float* dW2, int64_t lddw2, float* db2,
+                       void* stream)
 {
     if (n < 0 || n_out < 1 || n_out > 16 || !(H == 32 || H == 64 || H == 128)) return NGP_EINVAL;
+    if ((dW2 && (lddw2 < H || n_out > 4)) || (db2 && !dW2)) return NGP_EINVAL;
     if (n == 0) return NGP_OK;
     if (!out || !W2 || !hidden || !dz1) return NGP_EINVAL;
     if (((uintptr_t)hidden & 15) || ((uintptr_t)dz1 & 15) || (ldh % 4) || (lddz1 % 4)) return NGP_EINVAL;
     const int rows_per_block = 256 / (H / 4);
     int64_t blocks = (n + rows_per_block - 1) / rows_per_block;
     if (blocks > 8192) blocks = 8192;
+    if (dW2 && blocks > 1024) blocks = 1024;   // every block ends with one atomic per dW2 element
     hipStream_t st = (hipStream_t)stream;
-    if (n_out <= 4)
-        hipLaunchKernelGGL(mlp_hidden_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, dOut, lddo, out, ldo, act2,
-                           W2, ldw2, hidden, ldh, act1, n, H, n_out, dz2, lddz2, dz1, lddz1);
+    if (dW2)
+        hipLaunchKernelGGL((mlp_hidden_bwd_kernel<4, true>), dim3((unsigned)blocks), dim3(256), 0, st, dOut, lddo, out,
+                           ldo, act2, W2, ldw2, hidden, ldh, act1, n, H, n_out, dz2, lddz2, dz1, lddz1, dW2, lddw2, db2);
+    else if (n_out <= 4)
+        hipLaunchKernelGGL((mlp_hidden_bwd_kernel<4, false>), dim3((unsigned)blocks), dim3(256), 0, st, dOut, lddo, out,
+                           ldo, act2, W2, ldw2, hidden, ldh, act1, n, H, n_out, dz2, lddz2, dz1, lddz1, nullptr, 0,
+                           nullptr);
     else
-        hipLaunchKernelGGL(mlp_hidden_bwd_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, dOut, lddo, out, ldo, act2,
-                           W2, ldw2, hidden, ldh, act1, n, H, n_out, dz2, lddz2, dz1, lddz1);
+        hipLaunchKernelGGL((mlp_hidden_bwd_kernel<16, false>), dim3((unsigned)blocks), dim3(256), 0, st, dOut, lddo, out,
+                           ldo, act2, W2, ldw2, hidden, ldh, act1, n, H, n_out, dz2, lddz2, dz1, lddz1, nullptr, 0,
+                           nullptr);
     return ngp_check_launch();
 }
 
@@ -999,9 +1106,10 @@ int ngp_mlp_bwd_input(const float* dz2, int64_t lddz2, const float* W2, int64_t 
 
 int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t ldw2, const float* hidden,
                        int64_t ldh, int act1, const float* x, int64_t ldx, int64_t n, int n_in, int H, int n_out,
-                       float* dW1, int64_t ldw, float* db1, void* stream)
+                       float* dW1, int64_t ldw, float* db1, float* dW2, int64_t lddw2, float* db2, void* stream)
 {
-    if (n < 0 || n_in < 1 || !xf_args_ok(dz2, lddz2, W2, ldw2, hidden, ldh, H, n_out) || ldx < n_in || ldw < n_in)
+    if (n < 0 || n_in < 1 || !xf_args_ok(dz2, lddz2, W2, ldw2, hidden, ldh, H, n_out) || ldx < n_in || ldw < n_in ||
+        (dW2 && lddw2 < H) || (db2 && !dW2))
         return NGP_EINVAL;
     if (n == 0) return NGP_OK;
     if (!x || !dW1) return NGP_EINVAL;
@@ -1010,6 +1118,7 @@ int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t
     p.M = H; p.N = n_in; p.K = n; p.bias_grad = db1;
     p.vecA = aligned16(hidden) && (ldh % 4 == 0); p.vecB = aligned16(x) && (ldx % 4 == 0);
     p.xf_dz2 = dz2; p.xf_lddz2 = lddz2; p.xf_W2 = W2; p.xf_ldw2 = ldw2; p.xf_nout = n_out; p.xf_act = act1;
+    p.xf_dW2 = dW2; p.xf_lddw2 = lddw2; p.xf_db2 = db2;
     if (n_out == 1) launch_wgrad<1>(p, (hipStream_t)stream);
     else if (n_out <= 3) launch_wgrad<3>(p, (hipStream_t)stream);
     else launch_wgrad<XF_OMAX>(p, (hipStream_t)stream);

@@ -110,23 +110,30 @@ def _mlp2_backward(d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, l
         # dz1 = act1'(hidden) * (dz2 . W2) is formed inside the two first-layer products
         dz2 = torch.empty(n, n_out, dtype=_f32, device=dev)
         call("act_bwd", d_out, out, n * n_out, act2, dz2)
-        call("linear_bwd_weight", dz2, n_out, hidden, H, n, H, n_out, dW2, H, db2)
         if before_products is not None:
             before_products()
+        # the first-layer weight product streams dz2 and hidden anyway: it also leaves dW2 / db2
         if wide:
-            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, 128, H, n_out, dW1, ldw1, db1)
-            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_rem, ld_in, n, rem, H, n_out, dW1_rem, ldw1, None)
+            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, 128, H, n_out, dW1, ldw1, db1,
+                 dW2, H, db2)
+            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_rem, ld_in, n, rem, H, n_out, dW1_rem, ldw1, None,
+                 None, 0, None)
         else:
-            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, n_in, H, n_out, dW1, ldw1, db1)
+            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, n_in, H, n_out, dW1, ldw1, db1,
+                 dW2, H, db2)
         if dx is not None:
             call("mlp_bwd_input", dz2, n_out, W2, H, hidden, H, act1, w1_dx, ldw1, n, dx_cols, H, n_out, dx, ld_dx,
                  1 if accumulate else 0)
         return
     dz2 = torch.empty(n, 16 if n_out > 4 else 4, dtype=_f32, device=dev)
     dz1 = torch.empty(n, H, dtype=_f32, device=dev)
-    call("mlp_hidden_bwd", d_out, d_out.stride(0), out, ld_out, act2, W2, H, hidden, H, act1, n, H, n_out,
-         dz2, dz2.shape[1], dz1, H)
-    call("linear_bwd_weight", dz2, dz2.shape[1], hidden, H, n, H, n_out, dW2, H, db2)
+    if n_out <= 4:   # dW2 / db2 come out of the same pass over the hidden activations
+        call("mlp_hidden_bwd", d_out, d_out.stride(0), out, ld_out, act2, W2, H, hidden, H, act1, n, H, n_out,
+             None, 0, dz1, H, dW2, H, db2)
+    else:
+        call("mlp_hidden_bwd", d_out, d_out.stride(0), out, ld_out, act2, W2, H, hidden, H, act1, n, H, n_out,
+             dz2, dz2.shape[1], dz1, H, None, 0, None)
+        call("linear_bwd_weight", dz2, dz2.shape[1], hidden, H, n, H, n_out, dW2, H, db2)
     if before_products is not None:
         before_products()
     if wide:
@@ -224,7 +231,8 @@ class _FieldFn(Function):
             dz1 = None
         else:
             dz1 = torch.empty(n, 128, dtype=_f32, device=dev)
-            call("mlp_hidden_bwd", None, 0, sig, 1, _SOFTPLUS, W2, 128, a1, 128, _SOFTPLUS, n, 128, 1, None, 0, dz1, 128)
+            call("mlp_hidden_bwd", None, 0, sig, 1, _SOFTPLUS, W2, 128, a1, 128, _SOFTPLUS, n, 128, 1, None, 0, dz1, 128,
+                 None, 0, None)
             call("linear_bwd_input", dz1, 128, W1, 128, n, 128, 128, dfeat, 128, 0)
         grads = torch.empty(n, 3, dtype=_f32, device=dev)   # d sigma / d xn (normalised coordinates)
         call("grid_bwd_input", xe.desc, xyz_table, xn, dfeat, 128, n, grads)

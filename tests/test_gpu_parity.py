@@ -565,9 +565,30 @@ def test_mlp_fused_first_layer_backward(ngp, case):
     close(N(dx), 2 * ref_dx, 2e-5, 4e-5 * np.abs(ref_dx).max())      # accumulate
     dW = torch.zeros(H, n_in, device=DEV)
     db = torch.zeros(H, device=DEV)
-    call("mlp_bwd_weight", T(dz2), n_out, T(W2), H, T(hidden), H, act1, T(x), n_in, n, n_in, H, n_out, dW, n_in, db)
+    dW2 = torch.zeros(n_out, H, device=DEV)
+    db2 = torch.zeros(n_out, device=DEV)
+    call("mlp_bwd_weight", T(dz2), n_out, T(W2), H, T(hidden), H, act1, T(x), n_in, n, n_in, H, n_out, dW, n_in, db,
+         dW2, H, db2)
     close(N(dW), ref_dW, 2e-5, 2e-5 * np.abs(ref_dW).max())
     close(N(db), ref_db, 2e-5, 2e-5 * np.abs(ref_db).max())
+    # second-layer gradients from the same pass: dW2 = dz2^T . hidden, db2 = colsum(dz2)
+    ref_dW2 = dz2.astype(np.float64).T @ hidden.astype(np.float64)
+    close(N(dW2), ref_dW2, 2e-5, 2e-5 * np.abs(ref_dW2).max())
+    close(N(db2), dz2.astype(np.float64).sum(0), 2e-5, 2e-5 * np.abs(dz2).sum(0).max())
+    # plain route: ngp_mlp_hidden_bwd materialises dz1 and can leave dW2 / db2 as well
+    d_out = g.normal(size=(n, n_out)).astype(np.float32)
+    out = (1 / (1 + np.exp(-g.normal(size=(n, n_out))))).astype(np.float32)     # sigmoid outputs
+    dz2p = d_out.astype(np.float64) * out * (1 - out)
+    dz1_ref = d * (dz2p @ W2.astype(np.float64))
+    dz1_t = torch.empty(n, H, device=DEV)
+    dW2p = torch.zeros(n_out, H, device=DEV)
+    db2p = torch.zeros(n_out, device=DEV)
+    call("mlp_hidden_bwd", T(d_out), n_out, T(out), n_out, 2, T(W2), H, T(hidden), H, act1, n, H, n_out, None, 0,
+         dz1_t, H, dW2p, H, db2p)
+    close(N(dz1_t), dz1_ref, 2e-5, 2e-5 * np.abs(dz1_ref).max())
+    ref = dz2p.T @ hidden.astype(np.float64)
+    close(N(dW2p), ref, 3e-5, 3e-5 * np.abs(ref).max())
+    close(N(db2p), dz2p.sum(0), 3e-5, 3e-5 * np.abs(dz2p).sum(0).max())
     # a column window of W1 / x (the trainer passes rgb_net's grid-feature columns only)
     if n_in >= 64:
         dxw = torch.empty(n, 32, device=DEV)

@@ -37,7 +37,7 @@ a1 = torch.randn(n, 128, device=dev); W2 = torch.randn(3, 128, device=dev); o3 =
 ms = timeit(lambda: call("linear_fwd", a1, 128, W2, 128, None, n, 128, 3, 2, o3, 3, None))
 print(f"skinny fwd 128->3 {ms:.3f} ms  {n*512/ms/1e6:.0f} GB/s")
 d3 = torch.randn(n, 3, device=dev); dz2 = torch.empty(n, 4, device=dev); dz1 = torch.empty(n, 128, device=dev)
-ms = timeit(lambda: call("mlp_hidden_bwd", d3, 3, o3, 3, 2, W2, 128, a1, 128, 1, n, 128, 3, dz2, 4, dz1, 128))
+ms = timeit(lambda: call("mlp_hidden_bwd", d3, 3, o3, 3, 2, W2, 128, a1, 128, 1, n, 128, 3, dz2, 4, dz1, 128, None, 0, None))
 print(f"hidden_bwd H=128 O=3 {ms:.3f} ms  {n*1024/ms/1e6:.0f} GB/s")
 dW2 = torch.zeros(3, 128, device=dev)
 ms = timeit(lambda: call("linear_bwd_weight", dz2, 4, a1, 128, n, 128, 3, dW2, 128, None))

@@ -24,13 +24,13 @@ for H, n_in, n_out, act1 in ((128, 128, 1, 3), (128, 160, 3, 1), (32, 128, 3, 1)
     dz2 = torch.empty(n, n_out, device=dev)
 
     def plain():
-        call("mlp_hidden_bwd", d_out, n_out, out, n_out, 2, W2, H, hidden, H, act1, n, H, n_out, dz2p, 4, dz1, H)
+        call("mlp_hidden_bwd", d_out, n_out, out, n_out, 2, W2, H, hidden, H, act1, n, H, n_out, dz2p, 4, dz1, H, None, 0, None)
         call("linear_bwd_weight", dz1, H, x, n_in, n, n_in, H, dW1, n_in, db1)
         call("linear_bwd_input", dz1, H, W1, n_in, n, n_in, H, dx, n_in, 0)
 
     def fused():
         call("act_bwd", d_out, out, n * n_out, 2, dz2)
-        call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x, n_in, n, n_in, H, n_out, dW1, n_in, db1)
+        call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x, n_in, n, n_in, H, n_out, dW1, n_in, db1, None, 0, None)
         call("mlp_bwd_input", dz2, n_out, W2, H, hidden, H, act1, W1, n_in, n, n_in, H, n_out, dx, n_in, 0)
 
     def timeit(fn, reps=20):
