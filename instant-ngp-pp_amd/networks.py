@@ -288,25 +288,36 @@ class _FieldFn(Function):
         need = ctx.needs_input_grad  # (model, x, d, embed_a, xyz_table, W1, b1, W2, b2, rgb_table, rgb_p, nrm_p, sem_p)
         g_x = g_emb = g_xyz = g_W1 = g_b1 = g_W2 = g_b2 = g_rgbt = g_rgbp = g_nrm = g_sem = None
         span = model.xyz_max - model.xyz_min
+        # A trainer that owns the gradient storage (NGPTrainer: one flat buffer, zeroed by its Adam
+        # launch) registers the MLP gradients as sinks: the weight products accumulate straight into
+        # them and autograd gets None — no zeros_like fill, no AccumulateGrad add per parameter.
+        sinks = getattr(model, "_grad_sinks", None)
+
+        def grad_buffer(name, like):
+            t = None if sinks is None else sinks.get(name)
+            if t is not None:
+                return t, None          # (accumulate here, return nothing to autograd)
+            z = torch.zeros(like, dtype=_f32, device=dev) if isinstance(like, tuple) else torch.zeros_like(like)
+            return z, z
 
         # ---- colour branch (rgb_net + the two heads) -> gradient w.r.t. [grid features | appearance code]
         dfeat_rgb = None
         W_cols = 128 + E
         if d_rgb is not None:
-            g_rgbp = torch.zeros_like(rgb_p)
+            acc_rgbp, g_rgbp = grad_buffer("rgb_p", rgb_p)
             dfeat_rgb = torch.empty(n, W_cols, dtype=_f32, device=dev)
             _mlp2_backward(d_rgb.contiguous(), rgb_o, 3, model.rgb_net.output_activation, rgb_p[128 * Kp:], a_r, 128,
-                           _RELU, 3, rgb_in, Kp, Kp, rgb_p, Kp, g_rgbp, g_rgbp[128 * Kp:], None, None,
+                           _RELU, 3, rgb_in, Kp, Kp, rgb_p, Kp, acc_rgbp, acc_rgbp[128 * Kp:], None, None,
                            dfeat_rgb, W_cols, W_cols, 16, False)
         for d_o, p, a_h, out, n_out, slot in ((d_np, nrm_p, a_n, np_o, 3, "nrm"), (d_sem, sem_p, a_s, sem_o, C, "sem")):
             if d_o is None:
                 continue
-            g_p = torch.zeros_like(p)
+            acc_p, g_p = grad_buffer(slot + "_p", p)
             first = dfeat_rgb is None
             if first:
                 dfeat_rgb = torch.zeros(n, W_cols, dtype=_f32, device=dev) if E else torch.empty(n, W_cols, dtype=_f32, device=dev)
             _mlp2_backward(d_o.contiguous(), out, n_out, _NONE, p[32 * 128:], a_h, 32, _RELU, n_out,
-                           rgb_in[:, 16:], Kp, 128, p, 128, g_p, g_p[32 * 128:], None, None,
+                           rgb_in[:, 16:], Kp, 128, p, 128, acc_p, acc_p[32 * 128:], None, None,
                            dfeat_rgb, W_cols, 128, 0, not first)
             if slot == "nrm":
                 g_nrm = g_p
@@ -350,12 +361,11 @@ class _FieldFn(Function):
 
         # ---- density head
         if d_sig is not None:
-            g_W1, g_W2 = torch.zeros_like(W1), torch.zeros_like(W2)
-            g_b1 = torch.zeros(128, dtype=_f32, device=dev)
-            g_b2 = torch.zeros(1, dtype=_f32, device=dev)
+            (acc_W1, g_W1), (acc_W2, g_W2) = grad_buffer("W1", W1), grad_buffer("W2", W2)
+            (acc_b1, g_b1), (acc_b2, g_b2) = grad_buffer("b1", (128,)), grad_buffer("b2", (1,))
             dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
             _mlp2_backward(d_sig.contiguous().view(n, 1), sig, 1, _SOFTPLUS, W2, a1, 128, _SOFTPLUS, 1,
-                           feat, 128, 128, W1, 128, g_W1, g_W2, g_b1, g_b2, dfeat, 128, 128, 0, False,
+                           feat, 128, 128, W1, 128, acc_W1, acc_W2, acc_b1, acc_b2, dfeat, 128, 128, 0, False,
                            before_products=colour_scatter)
             if need[4]:
                 buf = getattr(xe, "grad_buffer", None)

@@ -177,6 +177,15 @@ class NGPTrainer:
         else:
             self.exp_avg = torch.zeros(total, dtype=_f32, device=dev)
             self.exp_avg_sq = torch.zeros(total, dtype=_f32, device=dev)
+        # the field's weight products accumulate straight into these views of the flat gradient
+        # (networks._FieldFn.backward); autograd then has nothing to add for them
+        m = self.model
+        import os as _os
+        if hasattr(m, "xyz_net") and hasattr(m, "rgb_net") and _os.environ.get("NGP_NO_GRAD_SINKS", "0") != "1":
+            lin1, lin2 = m.xyz_net[0], m.xyz_net[2]
+            m._grad_sinks = {"W1": lin1.weight.grad, "b1": lin1.bias.grad, "W2": lin2.weight.grad, "b2": lin2.bias.grad,
+                             "rgb_p": m.rgb_net.params.grad, "nrm_p": m.norm_pred_header.params.grad,
+                             "sem_p": m.semantic_header.params.grad}
         # scatter kernels accumulate directly into the flat gradient (see tinycudann._GridFwd)
         for enc_name in ("rgb_encoder", "xyz_encoder"):
             enc = getattr(self.model, enc_name, None)
