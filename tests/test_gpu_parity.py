@@ -355,6 +355,54 @@ def test_grid_fwd_bwd(ngp, case):
     close(N(gp), rgp, 1e-4, 1e-4 * max(1.0, np.abs(rgp).max() * 0.01))
 
 
+@pytest.mark.parametrize("log2T", [14, 19])
+def test_grid_bwd_param_ray_ordered(ngp, log2T):
+    """The scatter keeps corner sums in a sliding 2x2x2 window while consecutive samples move by at
+    most one cell per axis.  Random points almost never do that, so this case feeds what training
+    feeds: samples marched along rays (step sqrt(3)/1024), in both directions along every axis,
+    axis-aligned rays (pure face moves), diagonal rays, a coarse-step ray (jumps of several cells ->
+    full flush), repeated positions, zero-gradient tails, ray boundaries inside a 32-sample chunk."""
+    from ngp_amd._lib import call
+    L, Fd, base = 16, 8, 16
+    pls = 1.3195079107728942
+    desc, n_params = oracle.grid_layout(L, Fd, log2T, base, pls)
+    g = rng(150 + log2T)
+    step = np.float32(3 ** 0.5 / 1024)
+    xs = []
+    dirs = [g.normal(size=3) for _ in range(300)]
+    dirs += [np.array(v, float) for v in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1),
+                                          (1, 1, 1), (-1, -1, -1), (1, -1, 0), (0, 1, -1))]
+    for i, d in enumerate(dirs):
+        d = d / np.linalg.norm(d)
+        o = g.random(3) * 0.5 + 0.25
+        cnt = int(g.integers(1, 90))                       # not a multiple of the chunk length
+        st = step * (5.0 if i % 17 == 0 else 1.0)          # some rays jump several fine cells per step
+        t = np.arange(cnt, dtype=np.float32) * st
+        pts = o[None, :] + d[None, :] * t[:, None]
+        if i % 11 == 0:
+            pts[cnt // 2:] = pts[cnt // 2]                  # stuck samples (identical positions)
+        xs.append(pts)
+    x = np.clip(np.concatenate(xs), 0.0, 1.0).astype(np.float32)
+    n = x.shape[0]
+    dy = g.normal(size=(n, L * Fd)).astype(np.float32)
+    dead = g.random(n) < 0.2
+    dy[dead] = 0.0                                          # samples behind the early-termination point
+    dy[:, 8:16][g.random(n) < 0.1] = 0.0                    # a level with zero gradient on some samples
+    ref = oracle.grid_bwd_param(desc, x, dy, n_params)
+    out = torch.zeros(n_params, device=DEV)
+    gd = ngp._lib.GridDesc()
+    assert ngp._lib.call_host("grid_layout", L, Fd, log2T, base, pls, gd) == n_params
+    call("grid_bwd_param", gd, T(x), T(dy), L * Fd, n, out)
+    scale = np.abs(ref).max()
+    close(N(out), ref, 1e-4, 2e-5 * scale)
+    # and the same through a wider gradient matrix (the field passes a column window)
+    wide = np.zeros((n, L * Fd + 24), np.float32)
+    wide[:, :L * Fd] = dy
+    out2 = torch.zeros(n_params, device=DEV)
+    call("grid_bwd_param", gd, T(x), T(wide), L * Fd + 24, n, out2)
+    close(N(out2), ref, 1e-4, 2e-5 * scale)
+
+
 def test_grid_double_backward(ngp):
     L, Fd, log2T, base, pls, n = 8, 8, 15, 16, 1.5, 600
     tcnn = ngp.tinycudann
