@@ -118,44 +118,36 @@ struct TileT {
         }
     }
     // XF: v holds hidden[row][k..k+3]; dz1 = act1'(hidden) * sum_o dz2[row][o] W2[o][k].
-    // xf_fetch issues the (prefetchable) loads of dz2 / W2 next to the tile's own, xform is pure ALU.
-    float d2[PASSES][XF_OMAX];
-    float w2[XF_OMAX][4];
-    template <int OM, class ArgsT>
-    __device__ __forceinline__ void xf_fetch(const ArgsT& p, int64_t row0, int64_t rows, int64_t k0, int64_t kend)
+    // W2s [OM][128] (W2's columns k of this product) and D2s [ROWS][4] (dz2 of the block's rows) live
+    // in LDS, so nothing of the transform stays in registers across the MFMA loop.
+    template <int OM>
+    __device__ __forceinline__ void xform(int act, const float* __restrict__ W2s, const float* __restrict__ D2s,
+                                          int k_local, float (&)[XF_OMAX][4], float (&)[XF_OMAX], bool)
     {
         const int t = threadIdx.x;
-        const int64_t gk = k0 + (t % KQ) * 4;
+        const int kq = k_local + (t % KQ) * 4;
+        float w2[OM][4];
 #pragma unroll
-        for (int o = 0; o < OM; o++)
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                w2[o][j] = (o < p.xf_nout && gk + j < kend) ? p.xf_W2[o * p.xf_ldw2 + gk + j] : 0.0f;
+        for (int o = 0; o < OM; o++) {
+            const float4 q = *reinterpret_cast<const float4*>(W2s + o * 128 + kq);
+            w2[o][0] = q.x; w2[o][1] = q.y; w2[o][2] = q.z; w2[o][3] = q.w;
+        }
 #pragma unroll
         for (int pass = 0; pass < PASSES; pass++) {
             const int row = t / KQ + pass * RPP;
-            const int64_t gr = row0 + row;
+            if (row < ROWS) {
+                const float4 dq = *reinterpret_cast<const float4*>(D2s + row * 4);
+                const float d[4] = {dq.x, dq.y, dq.z, dq.w};
+                float sv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int o = 0; o < OM; o++)
-                d2[pass][o] = (row < ROWS && gr < rows && o < p.xf_nout) ? p.xf_dz2[gr * p.xf_lddz2 + o] : 0.0f;
+                for (int o = 0; o < OM; o++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sv[j] = fmaf(d[o], w2[o][j], sv[j]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[pass][j] = sv[j] * act_grad_fast(v[pass][j], act);
+            }
         }
     }
-    template <int OM>
-    __device__ __forceinline__ void xform(int act)
-    {
-#pragma unroll
-        for (int pass = 0; pass < PASSES; pass++) {
-            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int o = 0; o < OM; o++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) s[j] = fmaf(d2[pass][o], w2[o][j], s[j]);
-#pragma unroll
-            for (int j = 0; j < 4; j++) v[pass][j] = s[j] * act_grad_fast(v[pass][j], act);
-        }
-    }
-    template <int OM>
-    __device__ __forceinline__ void w2_accumulate(float (&)[XF_OMAX][4], float (&)[XF_OMAX]) const {}
     // dst[k][row], k-major with leading dimension LD
     template <int LD>
     __device__ __forceinline__ void commit(float* __restrict__ dst) const
@@ -204,55 +196,43 @@ struct TileD {
             }
         }
     }
-    // XF: v holds hidden[k][col..col+3] (k = sample row); W2's columns are fixed per thread
-    float d2[PASSES][XF_OMAX];
-    float w2[XF_OMAX][4];
-    template <int OM, class ArgsT>
-    __device__ __forceinline__ void xf_fetch(const ArgsT& p, int64_t col0, int64_t cols, int64_t k0, int64_t kend)
+    // XF: v holds hidden[k][col..col+3] (k = sample row).  W2s [OM][128] holds W2's columns of this
+    // block's m range, D2s [BK][4] the dz2 rows of the CURRENT K tile (double buffered by the caller).
+    // With W2G the second layer's weight gradient is accumulated from the raw tile on the way:
+    // gw[o][j] += dz2[k][o] * hidden[k][col+j], gb[o] += dz2[k][o].
+    template <int OM>
+    __device__ __forceinline__ void xform(int act, const float* __restrict__ W2s, const float* __restrict__ D2s,
+                                          int, float (&gw)[XF_OMAX][4], float (&gb)[XF_OMAX], bool w2g)
     {
         const int t = threadIdx.x;
-        const int64_t gc = col0 + (t % TPR) * 4;
+        const int c4 = (t % TPR) * 4;
+        float w2[OM][4];
 #pragma unroll
-        for (int o = 0; o < OM; o++)
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                w2[o][j] = (o < p.xf_nout && gc + j < cols) ? p.xf_W2[o * p.xf_ldw2 + gc + j] : 0.0f;
+        for (int o = 0; o < OM; o++) {
+            const float4 q = *reinterpret_cast<const float4*>(W2s + o * 128 + c4);
+            w2[o][0] = q.x; w2[o][1] = q.y; w2[o][2] = q.z; w2[o][3] = q.w;
+        }
 #pragma unroll
         for (int pass = 0; pass < PASSES; pass++) {
             const int kr = t / TPR + pass * RPP;
-            const int64_t gk = k0 + kr;
+            if (kr < BK) {
+                const float4 dq = *reinterpret_cast<const float4*>(D2s + kr * 4);
+                const float d[4] = {dq.x, dq.y, dq.z, dq.w};
+                float sv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int o = 0; o < OM; o++)
-                d2[pass][o] = (kr < BK && gk < kend && o < p.xf_nout) ? p.xf_dz2[gk * p.xf_lddz2 + o] : 0.0f;
-        }
-    }
-    template <int OM>
-    __device__ __forceinline__ void xform(int act)
-    {
+                for (int o = 0; o < OM; o++) {
+                    if (w2g) {
+                        gb[o] += d[o];
 #pragma unroll
-        for (int pass = 0; pass < PASSES; pass++) {
-            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        for (int j = 0; j < 4; j++) gw[o][j] = fmaf(d[o], v[pass][j], gw[o][j]);
+                    }
 #pragma unroll
-            for (int o = 0; o < OM; o++)
+                    for (int j = 0; j < 4; j++) sv[j] = fmaf(d[o], w2[o][j], sv[j]);
+                }
 #pragma unroll
-                for (int j = 0; j < 4; j++) s[j] = fmaf(d2[pass][o], w2[o][j], s[j]);
-#pragma unroll
-            for (int j = 0; j < 4; j++) v[pass][j] = s[j] * act_grad_fast(v[pass][j], act);
-        }
-    }
-    // second-layer weight gradient from the tile that is in registers anyway (raw hidden, before
-    // xform): gw[o][j] += dz2[k][o] * hidden[k][col+j]; gb[o] += dz2[k][o] (zero rows are zero)
-    template <int OM>
-    __device__ __forceinline__ void w2_accumulate(float (&gw)[XF_OMAX][4], float (&gb)[XF_OMAX]) const
-    {
-#pragma unroll
-        for (int pass = 0; pass < PASSES; pass++)
-#pragma unroll
-            for (int o = 0; o < OM; o++) {
-                gb[o] += d2[pass][o];
-#pragma unroll
-                for (int j = 0; j < 4; j++) gw[o][j] = fmaf(d2[pass][o], v[pass][j], gw[o][j]);
+                for (int j = 0; j < 4; j++) v[pass][j] = sv[j] * act_grad_fast(v[pass][j], act);
             }
+        }
     }
     template <int LD>
     __device__ __forceinline__ void commit(float* __restrict__ dst) const
@@ -273,9 +253,11 @@ struct TileD {
 template <bool TRANSPOSED, int EXT> struct TileSel { typedef TileT<EXT> type; };
 template <int EXT> struct TileSel<false, EXT> { typedef TileD<EXT> type; };
 
-template <int MODE, int WM, int WN, int TM, int TN, int XF, int F2 = 0>   // XF / F2 = width of the fused second layer (0: plain)
+template <int MODE, int WM, int WN, int TM, int TN, int XFW, int F2 = 0>   // XFW / F2 = width of the fused second layer (0: plain); XFW + 16: WGRAD also leaves dW2 / db2
 __device__ __forceinline__ void gemm_body(const GemmArgs& p)
 {
+    constexpr int XF = XFW & 15;
+    constexpr bool W2G = (XFW & 16) != 0;
     static_assert(!XF || MODE != MODE_FWD, "the operand transform exists for DGRAD / WGRAD only");
     static_assert(!F2 || MODE == MODE_FWD, "the second-layer epilogue exists for FWD only");
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
@@ -307,7 +289,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p)
     typename TileSel<MODE == MODE_FWD, BN>::type tb;
     float bias_acc = 0.0f; // WGRAD: column sums of dz for db (blockIdx.y == 0 only)
     const bool want_db = MODE == MODE_WGRAD && p.bias_grad != nullptr && blockIdx.y == 0;
-    const bool want_w2 = XF != 0 && MODE == MODE_WGRAD && p.xf_dW2 != nullptr && blockIdx.y == 0;
+    const bool want_w2 = W2G && XF != 0 && MODE == MODE_WGRAD && p.xf_dW2 != nullptr && blockIdx.y == 0;
     float gw2[XF_OMAX][4], gb2[XF_OMAX];
 #pragma unroll
     for (int o = 0; o < XF_OMAX; o++) {
@@ -317,17 +299,57 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p)
     }
 
     ta.fetch(p.A, p.lda, m0, p.M, kbeg, kend, p.vecA);
-    if (XF) ta.template xf_fetch<XF>(p, m0, p.M, kbeg, kend);
     tb.fetch(p.B, p.ldb, n0, p.N, kbeg, kend, p.vecB);
-    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        if (XF && MODE == MODE_WGRAD && want_w2) ta.template w2_accumulate<XF>(gw2, gb2);
-        if (XF) ta.template xform<XF>(p.xf_act);   // hidden -> dz1 in registers, on its way to LDS
+
+    // XF staging in LDS: W2's columns for this block, and dz2 — for DGRAD the block's rows (fixed),
+    // for WGRAD the rows of one K tile at a time, double buffered and prefetched like the tile itself
+    __shared__ float W2s[XF ? XF * 128 : 1];
+    __shared__ float D2s[XF ? (MODE == MODE_WGRAD ? 2 * BK * 4 : 128 * 4) : 1];
+    float d2pre[XF ? XF : 1];
+    auto d2_fetch = [&](int64_t k0) {      // WGRAD: dz2 rows k0 .. k0+BK-1, one row per thread
+        if (threadIdx.x < BK) {
+            const int64_t gk = k0 + threadIdx.x;
+#pragma unroll
+            for (int o = 0; o < XF; o++)
+                d2pre[o] = (gk < kend && o < p.xf_nout) ? p.xf_dz2[gk * p.xf_lddz2 + o] : 0.0f;
+        }
+    };
+    auto d2_commit = [&](int buf) {
+        if (threadIdx.x < BK) {
+#pragma unroll
+            for (int o = 0; o < 4; o++) D2s[(buf * BK + threadIdx.x) * 4 + o] = o < XF ? d2pre[o < XF ? o : 0] : 0.0f;
+        }
+    };
+    if constexpr (XF != 0) {
+        for (int idx = threadIdx.x; idx < XF * 128; idx += 256) {
+            const int o = idx >> 7, c = idx & 127;
+            const int64_t col = (MODE == MODE_WGRAD ? m0 : 0) + c;
+            const int64_t lim = MODE == MODE_WGRAD ? p.M : p.K;
+            W2s[idx] = (o < p.xf_nout && col < lim) ? p.xf_W2[o * p.xf_ldw2 + col] : 0.0f;
+        }
+        if (MODE == MODE_WGRAD) {
+            d2_fetch(kbeg);
+            d2_commit(0);
+        } else {
+            for (int idx = threadIdx.x; idx < 128 * 4; idx += 256) {
+                const int row = idx >> 2, o = idx & 3;
+                const int64_t gr = m0 + row;
+                D2s[idx] = (row < BM && gr < p.M && o < p.xf_nout && o < XF) ? p.xf_dz2[gr * p.xf_lddz2 + o] : 0.0f;
+            }
+        }
+        __syncthreads();
+    }
+    int it = 0;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK, it++) {
+        if constexpr (XF != 0)   // hidden -> dz1 in registers, on its way to LDS (+ dW2 / db2 partials for WGRAD)
+            ta.template xform<XF>(p.xf_act, W2s, D2s + (MODE == MODE_WGRAD ? (it & 1) * BK * 4 : 0), (int)(k0 - kbeg),
+                                  gw2, gb2, want_w2);
         ta.template commit<LDA>(As);
         tb.template commit<LDB>(Bs);
         __syncthreads();
         if (k0 + BK < kend) {
             ta.fetch(p.A, p.lda, m0, p.M, k0 + BK, kend, p.vecA);
-            if (XF) ta.template xf_fetch<XF>(p, m0, p.M, k0 + BK, kend);
+            if constexpr (XF != 0 && MODE == MODE_WGRAD) d2_fetch(k0 + BK);
             tb.fetch(p.B, p.ldb, n0, p.N, k0 + BK, kend, p.vecB);
         }
         if (want_db && threadIdx.x < BM) {
@@ -347,10 +369,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p)
                 for (int tn = 0; tn < TN; tn++)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
         }
+        if constexpr (XF != 0 && MODE == MODE_WGRAD) { if (k0 + BK < kend) d2_commit((it + 1) & 1); }
         __syncthreads();
     }
     if (want_db && threadIdx.x < BM && m0 + threadIdx.x < p.M) atomicAdd(p.bias_grad + m0 + threadIdx.x, bias_acc);
-    if (XF != 0 && MODE == MODE_WGRAD) {
+    if constexpr (W2G && XF != 0 && MODE == MODE_WGRAD) {
         // dW2 / db2 partials: threads with the same column quad (t % TPR) meet in LDS (the staging
         // tiles are free: the K loop ended with a barrier), one atomic per output element and block
         constexpr int TPR = BM / 4;             // threads per k-row of the A tile
@@ -385,7 +408,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p)
         }
     }
 
-    if (F2) {
+    if constexpr (F2 != 0) {
         // hidden tile: bias + activation + store as usual; second layer: every lane forms the partial
         // dot products of its TN columns for its 16 rows, a transposing butterfly over the 32 lanes
         // of the half-wave (16 shuffles per output instead of 16 x 5) leaves one row total per
@@ -891,6 +914,7 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 #define LAUNCH_GEMM(MODE, WM, WN, TM, TN)                                                                   \
     do {                                                                                                   \
         if (XF == 0) hipLaunchKernelGGL((gemm_kernel<MODE, WM, WN, TM, TN>), grid, dim3(256), 0, st, p);      \
+        else if (p.xf_dW2) hipLaunchKernelGGL((gemm_xf_kernel<MODE, WM, WN, TM, TN, (XF ? XF : 1) + (MODE == MODE_WGRAD ? 16 : 0)>), grid, dim3(256), 0, st, p); \
         else hipLaunchKernelGGL((gemm_xf_kernel<MODE, WM, WN, TM, TN, (XF ? XF : 1)>), grid, dim3(256), 0, st, p); \
     } while (0)
 

@@ -77,10 +77,9 @@ import os as _os
 _OVERLAP = _os.environ.get("NGP_NO_OVERLAP", "0") != "1"
 _FUSED_FWD = _os.environ.get("NGP_NO_FUSED_FWD", "0") != "1"   # A/B switch for ngp_mlp2_fwd
 _FUSED_BWD = _os.environ.get("NGP_NO_FUSED_BWD", "0") != "1"   # A/B switch for the operand-transform products
-# widest second layer that takes the fused route: measured on MI355X (tools/mlp_bwd_microbench.py,
-# n = 433 k) the density head (1 output) gains 16 % (0.53 -> 0.45 ms), 3 outputs lose 6 % (the
-# extra staging registers spill at 3 workgroups per CU), so rgb_net and the headers stay on the plain route
-_FUSED_BWD_MAX_OUT = int(_os.environ.get("NGP_FUSED_BWD_MAX_OUT", "1"))
+# widest second layer that takes the fused route (tools/mlp_bwd_microbench.py, n = 433 k, MI355X):
+# density head 0.54 -> 0.49 ms, rgb_net 0.60 -> 0.57 ms, 32-wide headers 0.22 -> 0.22 ms
+_FUSED_BWD_MAX_OUT = int(_os.environ.get("NGP_FUSED_BWD_MAX_OUT", "3"))
 _SIDE = {}
 
 
@@ -114,10 +113,12 @@ def _mlp2_backward(d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, l
             before_products()
         # the first-layer weight product streams dz2 and hidden anyway: it also leaves dW2 / db2
         if wide:
+            # dW2 / db2 ride with the narrow remainder launch (16 accumulator registers per lane; in the
+            # 128x128 one the extra partial sums would spill at 3 workgroups per CU)
             call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, 128, H, n_out, dW1, ldw1, db1,
-                 dW2, H, db2)
-            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_rem, ld_in, n, rem, H, n_out, dW1_rem, ldw1, None,
                  None, 0, None)
+            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_rem, ld_in, n, rem, H, n_out, dW1_rem, ldw1, None,
+                 dW2, H, db2)
         else:
             call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, n_in, H, n_out, dW1, ldw1, db1,
                  dW2, H, db2)
