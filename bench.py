@@ -227,6 +227,12 @@ def main():
                     t_ms, fl = sum(m for m, _ in sel), sum(f for _, f in sel)
                     kern[name] = {"launches": len(sel), "total_ms": t_ms, "avg_ms": t_ms / len(sel),
                                   "TFLOPs": fl / (t_ms * 1e-3) / 1e12}
+            elif name == "adam_step":
+                # 4 streams read + 4 written per parameter (p, g, m, v; the gradient is zeroed): 32 B each;
+                # the parameter count is the first int argument
+                tot_b = sum(32.0 * a[0] for _, _, a in evs)
+                kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
+                              "GBps": tot_b / (sum(ms) * 1e-3) / 1e9, "frac_of_hbm_peak": tot_b / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
             else:
                 kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms)}
         grid_names = [k for k in kern if k.startswith("grid")]
