@@ -953,6 +953,38 @@ def test_train_from_dataset_directory(ngp, tmp_path):
     assert len(psnrs) == 2 and min(psnrs) > 22.0, psnrs
 
 
+def test_trainer_fused_loss_path_matches_module_path(ngp):
+    """NGPTrainer with the fused loss kernels (directly seeded backward) follows the same
+    trajectory as with the reference's NeRFLoss module + loss.backward()."""
+    from ngp_amd.synthetic import LegoProxy
+    from ngp_amd.trainer import NGPTrainer
+    scene = LegoProxy(n_images=10, img_wh=(100, 100), device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(51)
+    batches = []
+    for i in range(6):
+        img, pix = scene.sample_batch(1024, generator=gen)
+        o, d = scene.rays(img, pix)
+        gt, _ = scene.ground_truth(o, d, n_quad=64)
+        batches.append((o, d, gt))
+    out = []
+    for fused in (True, False):
+        torch.manual_seed(52)
+        model = ngp.networks.NGP(scale=0.5).to(DEV)
+        G = model.grid_size
+        model.register_buffer("density_grid", torch.zeros(model.cascades, G ** 3, device=DEV))
+        coords = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=DEV)] * 3, indexing="ij"), -1)
+        model.register_buffer("grid_coords", coords.reshape(-1, 3).contiguous())
+        tr = NGPTrainer(model, lr=1e-2)
+        tr.fused_loss = fused
+        torch.manual_seed(53)
+        losses = [float(tr.step(o, d, gt)[0]) for o, d, gt in batches]
+        tr.wait()
+        out.append((losses, N(model.xyz_net[0].weight).copy(), N(model.rgb_net.params).copy()))
+    close(np.array(out[0][0]), np.array(out[1][0]), 1e-3, 1e-7)
+    close(out[0][1], out[1][1], 5e-3, 5e-5)
+    close(out[0][2], out[1][2], 5e-3, 5e-5)
+
+
 def test_differentiable_normals_h4(ngp):
     """--normal_ref path: a loss on normals_raw reaches the density table through the grid's double
     backward; checked against a central difference along a random direction in parameter space."""
