@@ -985,6 +985,39 @@ def test_trainer_fused_loss_path_matches_module_path(ngp):
     close(out[0][2], out[1][2], 5e-3, 5e-5)
 
 
+def test_test_time_render_fast_loop_identical(ngp):
+    """render(test_time=True) runs the field on the marcher's padded blocks instead of compacting
+    with a mask and scattering back; every per-ray output must be bit-identical to the literal
+    reference loop (same rounds, same samples, row-independent field)."""
+    from ngp_amd.synthetic import LegoProxy
+    from ngp_amd.trainer import NGPTrainer
+    from ngp_amd.rendering import render
+    torch.manual_seed(61)
+    model = ngp.networks.NGP(scale=0.5).to(DEV)
+    G = model.grid_size
+    model.register_buffer("density_grid", torch.zeros(model.cascades, G ** 3, device=DEV))
+    coords = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=DEV)] * 3, indexing="ij"), -1)
+    model.register_buffer("grid_coords", coords.reshape(-1, 3).contiguous())
+    scene = LegoProxy(n_images=12, img_wh=(120, 120), device=DEV)
+    tr = NGPTrainer(model, lr=1e-2)
+    gen = torch.Generator(device=DEV).manual_seed(62)
+    for i in range(300):
+        img, pix = scene.sample_batch(2048, generator=gen)
+        o, d = scene.rays(img, pix)
+        gt, _ = scene.ground_truth(o, d, n_quad=64)
+        tr.step(o, d, gt)
+    tr.wait()
+    n = 120 * 120
+    o, d = scene.rays(torch.full((n,), 3, dtype=torch.long, device=DEV), torch.arange(n, device=DEV))
+    for thr in (1e-2, 1e-4):
+        fast = render(model, o, d, test_time=True, T_threshold=thr)
+        ref = render(model, o, d, test_time=True, T_threshold=thr, reference_test_loop=True)
+        assert int(fast["total_samples"]) == int(ref["total_samples"]) > 0
+        for k in ("opacity", "depth", "rgb", "normal_pred", "normal_raw", "semantic", "points"):
+            assert torch.equal(fast[k], ref[k]), k
+        assert float(fast["opacity"].max()) > 0.9
+
+
 def test_differentiable_normals_h4(ngp):
     """--normal_ref path: a loss on normals_raw reaches the density table through the grid's double
     backward; checked against a central difference along a random direction in parameter space."""
