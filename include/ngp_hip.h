@@ -306,9 +306,9 @@ int ngp_linear_fwd(const float* x, int64_t ldx, const float* W, int64_t ldw, con
                    void* stream);
 
 /* Forward of a 2-layer MLP in one launch: hidden (n, H<=128) = act1(x W1^T + b1) is stored (the
- * backward needs it), out (n, n_out<=4) = act2(hidden W2^T + b2) is formed from the activated tile
+ * backward needs it), out (n, n_out<=8) = act2(hidden W2^T + b2) is formed from the activated tile
  * in the MFMA kernel's epilogue — xyz_net (networks.py:54-59), rgb_net (89-100), norm_pred_header
- * (102-111).  b1 / b2 may be NULL (tcnn networks have no biases). */
+ * (102-111), semantic_header (114-123, up to 8 classes).  b1 / b2 may be NULL (tcnn networks have no biases). */
 int ngp_mlp2_fwd(const float* x, int64_t ldx, const float* W1, int64_t ldw1, const float* b1, int act1,
                  const float* W2, int64_t ldw2, const float* b2, int act2, int64_t n, int n_in, int H,
                  int n_out, float* hidden, int64_t ldh, float* out, int64_t ldo, void* stream);

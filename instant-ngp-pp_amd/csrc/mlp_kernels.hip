@@ -414,48 +414,54 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p)
         // of the half-wave (16 shuffles per output instead of 16 x 5) leaves one row total per
         // lane pair, the WN column halves meet in LDS (the staging tiles are free by now).
         float* red = As;   // [WN][BM][F2]
+        constexpr int OGW = F2 < 4 ? F2 : 4;            // outputs per pass over the tile
+        constexpr int OGN = (F2 + OGW - 1) / OGW;       // passes (8 outputs: two passes of four keep 64 partial sums)
 #pragma unroll
         for (int tm = 0; tm < TM; tm++) {
-            float part[F2 ? F2 : 1][16];
 #pragma unroll
-            for (int o = 0; o < F2; o++)
+            for (int og = 0; og < OGN; og++) {
+                float part[OGW][16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) part[o][r] = 0.0f;
+                for (int o = 0; o < OGW; o++)
 #pragma unroll
-            for (int tn = 0; tn < TN; tn++) {
-                const int64_t n = n0 + (wn * TN + tn) * 32 + li;
-                const bool ncol = n < p.N;
-                const float bv = (ncol && p.bias) ? p.bias[n] : 0.0f;
-                float w2[F2 ? F2 : 1];
+                    for (int r = 0; r < 16; r++) part[o][r] = 0.0f;
 #pragma unroll
-                for (int o = 0; o < F2; o++) w2[o] = (ncol && o < p.f2_nout) ? p.f2_W2[o * p.f2_ldw2 + n] : 0.0f;
+                for (int tn = 0; tn < TN; tn++) {
+                    const int64_t n = n0 + (wn * TN + tn) * 32 + li;
+                    const bool ncol = n < p.N;
+                    const float bv = (ncol && p.bias) ? p.bias[n] : 0.0f;
+                    float w2[OGW];
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float v = act_fwd(acc[tm][tn][r] + bv, p.act);
-                    if (ncol && m < p.M) p.C[m * p.ldc + n] = v;
+                    for (int o = 0; o < OGW; o++)
+                        w2[o] = (ncol && og * OGW + o < p.f2_nout) ? p.f2_W2[(og * OGW + o) * p.f2_ldw2 + n] : 0.0f;
 #pragma unroll
-                    for (int o = 0; o < F2; o++) part[o][r] = fmaf(v, w2[o], part[o][r]);
-                }
-            }
+                    for (int r = 0; r < 16; r++) {
+                        const int64_t m = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float v = act_fwd(acc[tm][tn][r] + bv, p.act);
+                        if (og == 0 && ncol && m < p.M) p.C[m * p.ldc + n] = v;
 #pragma unroll
-            for (int o = 0; o < F2; o++) {
-                float* v = part[o];
-#pragma unroll
-                for (int half = 8; half >= 1; half >>= 1) {
-                    const int mask = half * 2;   // 16, 8, 4, 2
-                    const bool up = (li & mask) != 0;
-#pragma unroll
-                    for (int j = 0; j < half; j++) {
-                        const float keep = up ? v[j + half] : v[j];
-                        const float send = up ? v[j] : v[j + half];
-                        v[j] = keep + __shfl_xor(send, mask, 64);
+                        for (int o = 0; o < OGW; o++) part[o][r] = fmaf(v, w2[o], part[o][r]);
                     }
                 }
-                const float tot = v[0] + __shfl_xor(v[0], 1, 64);
-                const int rr = ((li >> 4) & 1) * 8 + ((li >> 3) & 1) * 4 + ((li >> 2) & 1) * 2 + ((li >> 1) & 1);
-                const int row = (wm * TM + tm) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-                if ((li & 1) == 0) red[(wn * BM + row) * F2 + o] = tot;
+#pragma unroll
+                for (int o = 0; o < OGW; o++) {
+                    float* v = part[o];
+#pragma unroll
+                    for (int half = 8; half >= 1; half >>= 1) {
+                        const int mask = half * 2;   // 16, 8, 4, 2
+                        const bool up = (li & mask) != 0;
+#pragma unroll
+                        for (int j = 0; j < half; j++) {
+                            const float keep = up ? v[j + half] : v[j];
+                            const float send = up ? v[j] : v[j + half];
+                            v[j] = keep + __shfl_xor(send, mask, 64);
+                        }
+                    }
+                    const float tot = v[0] + __shfl_xor(v[0], 1, 64);
+                    const int rr = ((li >> 4) & 1) * 8 + ((li >> 3) & 1) * 4 + ((li >> 2) & 1) * 2 + ((li >> 1) & 1);
+                    const int row = (wm * TM + tm) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                    if ((li & 1) == 0) red[(wn * BM + row) * F2 + og * OGW + o] = tot;
+                }
             }
         }
         __syncthreads();
@@ -1002,7 +1008,7 @@ int ngp_mlp2_fwd(const float* x, int64_t ldx, const float* W1, int64_t ldw1, con
                  const float* W2, int64_t ldw2, const float* b2, int act2, int64_t n, int n_in, int H, int n_out,
                  float* hidden, int64_t ldh, float* out, int64_t ldo, void* stream)
 {
-    if (n < 0 || n_in < 1 || H < 1 || H > 128 || n_out < 1 || n_out > 4 || ldx < n_in || ldw1 < n_in || ldh < H ||
+    if (n < 0 || n_in < 1 || H < 1 || H > 128 || n_out < 1 || n_out > 8 || ldx < n_in || ldw1 < n_in || ldh < H ||
         ldw2 < H || ldo < n_out)
         return NGP_EINVAL;
     if (n == 0) return NGP_OK;
@@ -1016,10 +1022,12 @@ int ngp_mlp2_fwd(const float* x, int64_t ldx, const float* W1, int64_t ldw1, con
     dim3 grid(ngp_blocks(n, 128), 1);
     if (H > 32) {
         if (n_out == 1) hipLaunchKernelGGL((gemm_fwd2_kernel<2, 2, 2, 2, 1>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_fwd2_kernel<2, 2, 2, 2, 4>), grid, dim3(256), 0, st, p);
+        else if (n_out <= 4) hipLaunchKernelGGL((gemm_fwd2_kernel<2, 2, 2, 2, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_fwd2_kernel<2, 2, 2, 2, 8>), grid, dim3(256), 0, st, p);
     } else {
         if (n_out == 1) hipLaunchKernelGGL((gemm_fwd2_kernel<4, 1, 1, 1, 1>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_fwd2_kernel<4, 1, 1, 1, 4>), grid, dim3(256), 0, st, p);
+        else if (n_out <= 4) hipLaunchKernelGGL((gemm_fwd2_kernel<4, 1, 1, 1, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_fwd2_kernel<4, 1, 1, 1, 8>), grid, dim3(256), 0, st, p);
     }
     return ngp_check_launch();
 }

@@ -265,9 +265,13 @@ class _FieldFn(Function):
             call("linear_fwd", feat_rgb, Kp, nrm_p, 128, None, n, 128, 32, _RELU, a_n, 32, None)
             call("linear_fwd", a_n, 32, nrm_p[32 * 128:], 32, None, n, 32, 3, _NONE, np_o, 3, None)
         a_s = torch.empty(n, 32, dtype=_f32, device=dev)
-        call("linear_fwd", feat_rgb, Kp, sem_p, 128, None, n, 128, 32, _RELU, a_s, 32, None)
         sem_o = torch.empty(n, C, dtype=_f32, device=dev)
-        call("linear_fwd", a_s, 32, sem_p[32 * 128:], 32, None, n, 32, C, _NONE, sem_o, C, None)
+        if _FUSED_FWD and C <= 8:
+            call("mlp2_fwd", feat_rgb, Kp, sem_p, 128, None, _RELU, sem_p[32 * 128:], 32, None, _NONE,
+                 n, 128, 32, C, a_s, 32, sem_o, C)
+        else:
+            call("linear_fwd", feat_rgb, Kp, sem_p, 128, None, n, 128, 32, _RELU, a_s, 32, None)
+            call("linear_fwd", a_s, 32, sem_p[32 * 128:], 32, None, n, 32, C, _NONE, sem_o, C, None)
 
         ctx.model = model
         ctx.E, ctx.K, ctx.Kp, ctx.C = E, K, Kp, C

@@ -531,6 +531,8 @@ def test_adam_matches_torch(ngp):
     (777, 128, 32, 3, 1, 0, False),      # norm_pred_header
     (130, 144, 128, 4, 1, 0, False),     # 4 outputs, two row tiles, second one ragged
     (5, 16, 64, 2, 1, 4, True),          # H = 64 (half-empty column tile), exp output
+    (900, 128, 32, 7, 1, 0, False),      # semantic_header: 7 classes (two passes of the epilogue)
+    (333, 128, 128, 8, 1, 0, True),      # 8 outputs on the wide tile
 ])
 def test_mlp2_fwd_fused(ngp, case):
     """ngp_mlp2_fwd (second layer applied in the MFMA kernel's epilogue) against fp64"""
