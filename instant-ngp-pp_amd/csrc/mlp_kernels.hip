@@ -1121,10 +1121,9 @@ int ngp_mlp_bwd_input(const float* dz2, int64_t lddz2, const float* W2, int64_t 
                       int64_t ldh, int act1, const float* W1, int64_t ldw1, int64_t n, int n_in, int H, int n_out,
                       float* dx, int64_t lddx, int accumulate, void* stream)
 {
-    if (n < 0 || n_in < 1 || !xf_args_ok(dz2, lddz2, W2, ldw2, hidden, ldh, H, n_out) || ldw1 < n_in || lddx < n_in)
-        return NGP_EINVAL;
-    if (n == 0) return NGP_OK;
-    if (!W1 || !dx) return NGP_EINVAL;
+    if (n < 0 || n_in < 1 || n_out < 1 || n_out > XF_OMAX || H < 8 || ldw1 < n_in || lddx < n_in) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;   // empty batches carry null pointers
+    if (!xf_args_ok(dz2, lddz2, W2, ldw2, hidden, ldh, H, n_out) || !W1 || !dx) return NGP_EINVAL;
     GemmArgs p{};
     p.A = hidden; p.lda = ldh; p.B = W1; p.ldb = ldw1; p.C = dx; p.ldc = lddx;
     p.M = n; p.N = n_in; p.K = H; p.accumulate = accumulate;
@@ -1140,11 +1139,11 @@ int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t
                        int64_t ldh, int act1, const float* x, int64_t ldx, int64_t n, int n_in, int H, int n_out,
                        float* dW1, int64_t ldw, float* db1, float* dW2, int64_t lddw2, float* db2, void* stream)
 {
-    if (n < 0 || n_in < 1 || !xf_args_ok(dz2, lddz2, W2, ldw2, hidden, ldh, H, n_out) || ldx < n_in || ldw < n_in ||
+    if (n < 0 || n_in < 1 || n_out < 1 || n_out > XF_OMAX || H < 8 || ldx < n_in || ldw < n_in ||
         (dW2 && lddw2 < H) || (db2 && !dW2))
         return NGP_EINVAL;
-    if (n == 0) return NGP_OK;
-    if (!x || !dW1) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;   // empty batches carry null pointers
+    if (!xf_args_ok(dz2, lddz2, W2, ldw2, hidden, ldh, H, n_out) || !x || !dW1) return NGP_EINVAL;
     GemmArgs p{};
     p.A = hidden; p.lda = ldh; p.B = x; p.ldb = ldx; p.C = dW1; p.ldc = ldw;
     p.M = H; p.N = n_in; p.K = n; p.bias_grad = db1;

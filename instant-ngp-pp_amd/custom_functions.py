@@ -99,6 +99,8 @@ class VolumeRenderer(torch.autograd.Function):
         d_rgbs = torch.empty(N, 3, dtype=_f32, device=dev)
         d_nrm = torch.empty(N, 3, dtype=_f32, device=dev) if dL_dnormal_pred is not None else None
         d_sems = torch.empty(N, classes, dtype=_f32, device=dev) if dL_dsem is not None else None
+        if N == 0:   # no sample in the batch (every ray missed the occupied cells): nothing to propagate
+            return d_sig, d_rgbs, d_nrm, d_sems, None, None, None, None, None
         call("composite_train_bw", z(dL_dopacity, nr), z(dL_ddepth, nr), z(dL_drgb, nr, 3),
              None if d_nrm is None else dL_dnormal_pred.contiguous(), None if d_sems is None else dL_dsem.contiguous(),
              z(dL_dws, N), sigmas, rgbs, normals_pred, ws, deltas, ts, rays_a, opacity, depth, rgb, normal_pred,

@@ -1020,6 +1020,27 @@ def test_test_time_render_fast_loop_identical(ngp):
         assert float(fast["opacity"].max()) > 0.9
 
 
+def test_render_with_no_samples(ngp):
+    """Edge case of the path: every cell empty -> the marcher returns zero samples; the train and
+    test renders still return well-formed (all-background) results and backward is a no-op."""
+    from ngp_amd.rendering import render
+    model = _make_model(ngp)
+    model.density_bitfield.zero_()
+    o, d = make_rays(300, scale=1.0, seed=71)
+    o, d = T(o), T(d)
+    res = render(model, o, d, exp_step_factor=0.0)
+    assert int(res["total_samples"]) == 0 and res["xyzs"].shape == (0, 3)
+    assert res["rgb"].shape == (300, 3) and not res["rgb"].any() and not res["opacity"].any()
+    loss = ((res["rgb"] - 0.5) ** 2).mean() + res["opacity"].mean()
+    loss.backward()                       # nothing to propagate into: must not fault
+    for p in model.parameters():
+        assert p.grad is None or not p.grad.any()
+    test = render(model, o, d, test_time=True, exp_step_factor=0.0)
+    assert int(test["total_samples"]) == 0 and not test["rgb"].any()
+    ref = render(model, o, d, test_time=True, exp_step_factor=0.0, reference_test_loop=True)
+    assert torch.equal(test["rgb"], ref["rgb"]) and torch.equal(test["opacity"], ref["opacity"])
+
+
 def test_differentiable_normals_h4(ngp):
     """--normal_ref path: a loss on normals_raw reaches the density table through the grid's double
     backward; checked against a central difference along a random direction in parameter space."""
