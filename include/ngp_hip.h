@@ -16,7 +16,11 @@
  *   - return 0 on success, a negative NGP_E* code on failure; never throws,
  *     never allocates, never synchronises the device, no hidden global state
  *     (safe to capture into a hipGraph);
- *   - all floating point is fp32, indices are int32/int64 as the reference's.
+ *   - all floating point is fp32, indices are int32/int64 as the reference's;
+ *   - empty batches (n == 0) are valid and return NGP_OK before any pointer is looked at;
+ *   - a few NGP_* environment variables, read once, select older kernel variants for A/B timing
+ *     (NGP_GRID_BWD_SIMPLE / _NOPAIR / _NOSLIDE, NGP_MARCH_LANE_PER_RAY, NGP_ADAM_BLOCKS,
+ *     NGP_WGRAD_BLOCKS); results are the same up to summation order.
  *
  * Each entry point cites the reference interface it replaces.
  */
