@@ -94,6 +94,9 @@ MARCH_CASES = [
     (5, 8.0, 1 / 256, 0.03, 1500, 1024),
     (6, 16.0, 1 / 256, 0.02, 700, 256),
     (1, 0.5, 0.0, 0.0, 64, 1024),       # empty grid: no samples at all
+    (6, 16.0, 0.0, 0.02, 300, 1024),    # constant fine step in a 32-wide box: chains of >10^4 elements, i.e. many
+                                        # 1024-element segments and skips that end beyond a segment (wave marcher)
+    (3, 2.0, 0.0, 0.3, 400, 128),       # dense occupancy with a small sample cap reached mid-segment
 ]
 
 
