@@ -40,6 +40,16 @@ for fn in ("ray_aabb_intersect", "ray_sphere_intersect", "morton3D", "morton3D_i
            "raymarching_test", "composite_alpha_fw", "composite_train_fw", "composite_train_bw", "composite_test_fw",
            "composite_refloss_fw", "composite_refloss_bw", "distortion_loss_fw", "distortion_loss_bw"):
     assert callable(getattr(vren, fn)), fn
+# the reference's loss module imports on this vren and carries the same weights as ours
+import importlib.util
+spec = importlib.util.spec_from_file_location("ref_losses", %(ref)r + "/losses.py")
+ref_losses = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(ref_losses)
+from ngp_amd.losses import NeRFLoss
+rl, ol = ref_losses.NeRFLoss(), NeRFLoss()
+for k in ("lambda_opa", "lambda_distortion", "lambda_depth_mono", "lambda_normal_mono", "lambda_normal_ref_rp",
+          "lambda_normal_ref_ro", "lambda_sky", "lambda_semantic"):
+    assert getattr(rl, k) == getattr(ol, k), k
 print("DROPIN_OK")
 '''
 
