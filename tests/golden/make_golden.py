@@ -196,6 +196,69 @@ def g5_raymarcher_bw(cf):
         dL_drays_o=out[0], dL_drays_d=out[1])
 
 
+def table_rule(n, amp=0.6):
+    """deterministic pseudo-random table of n floats in [-amp/2, amp/2): value_i = frac(i * phi32) - 0.5,
+    reproduced by the tests instead of storing 200 M numbers"""
+    i = np.arange(n, dtype=np.uint64)
+    return (((i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)).astype(np.float64) / 4294967296.0 - 0.5).astype(
+        np.float32) * np.float32(amp)
+
+
+def g6_ngp_field():
+    """The reference's OWN models/networks.py::NGP (forward / forward_test / density) evaluated on the
+    CPU: `tinycudann` is the pure-torch stand-in of tcnn_cpu_shim.py (checked against the C oracle
+    below), `vren` an empty module (the field's forward does not touch it).  Pins the PYTHON wiring of
+    the field: input normalisation, d(sigma)/dx normals through autograd, -F.normalize, head inputs,
+    SH of (normalize(d)+1)/2, column order of rgb_net's input, activations, forward_test's swap."""
+    sys.path.insert(0, OUT)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import tcnn_cpu_shim
+    import oracle
+    sys.modules["tinycudann"] = tcnn_cpu_shim
+    from models import networks as ref_net
+    cases = {}
+    for tag, kw in (("a", {"scale": 0.5}), ("b", {"scale": 8.0, "embed_a": True, "embed_a_len": 8})):
+        torch.manual_seed(SEED + 6)
+        model = ref_net.NGP(**kw)
+        g = np.random.default_rng(SEED + 7)
+        with torch.no_grad():
+            model.xyz_encoder.params.copy_(torch.from_numpy(table_rule(model.xyz_encoder.params.numel())))
+            model.rgb_encoder.params.copy_(torch.from_numpy(table_rule(model.rgb_encoder.params.numel())))
+            for name, p in model.named_parameters():
+                if name.startswith("xyz_net") or name in ("rgb_net.params", "norm_pred_header.params",
+                                                          "semantic_header.params"):
+                    p.copy_(torch.from_numpy((g.standard_normal(p.shape) * 0.15).astype(np.float32)))
+                    cases[f"{tag}_{name}"] = p.detach().clone()
+        # the stand-in encoder must be the C oracle's encoder (same level rule, index rule, layout)
+        desc, n_params = oracle.grid_layout(16, 8, 19, 16, float(np.exp(np.log(2048 * kw["scale"] / 16) / 15)))
+        assert n_params == model.xyz_encoder.params.numel()
+        xt = g.random((64, 3)).astype(np.float32)
+        a = model.xyz_encoder(torch.from_numpy(xt)).detach().numpy()
+        b = oracle.grid_fwd(desc, model.xyz_encoder.params.detach().numpy(), xt)
+        assert np.abs(a - b).max() < 2e-6 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+
+        n = 192
+        s = kw["scale"]
+        x = ((g.random((n, 3)) - 0.5) * 2 * s * 0.95).astype(np.float32)
+        x[: n // 2] *= 0.3 / s if s > 1 else 1.0
+        d = g.standard_normal((n, 3)).astype(np.float32)
+        kwargs = {}
+        if kw.get("embed_a"):
+            emb = g.standard_normal((n, 8)).astype(np.float32)
+            kwargs["embedding_a"] = torch.from_numpy(emb)
+            cases[f"{tag}_embedding_a"] = emb
+        cases[f"{tag}_x"], cases[f"{tag}_d"], cases[f"{tag}_scale"] = x, d, np.float64(s)
+        outs = model(torch.from_numpy(x.copy()), torch.from_numpy(d), **kwargs)
+        for k, v in zip(("sigmas", "rgbs", "normals_raw", "normals_pred", "semantic"), outs):
+            cases[f"{tag}_fwd_{k}"] = v.detach()
+        outs = model.forward_test(torch.from_numpy(x.copy()), torch.from_numpy(d), **kwargs)
+        for k, v in zip(("sigmas", "rgbs", "normals_pred", "normals_raw", "semantic"), outs):
+            cases[f"{tag}_test_{k}"] = v.detach()
+        with torch.no_grad():
+            cases[f"{tag}_density"] = model.density(torch.from_numpy(x.copy()))
+    npz("g6_ngp_field.npz", **cases)
+
+
 if __name__ == "__main__":
     cf, rn = import_reference()
     g1_raw2outputs(cf)
@@ -203,3 +266,4 @@ if __name__ == "__main__":
     g3_render(cf, rn)
     g4_activations(cf)
     g5_raymarcher_bw(cf)
+    g6_ngp_field()

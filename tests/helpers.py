@@ -58,3 +58,20 @@ def borderline_rays(sigmas, deltas, rays_a, T_thr, rel=1e-4):
         T = np.cumprod(1.0 - a)
         bad[i] = np.any(np.abs(T - T_thr) <= rel * max(T_thr, 1e-30))
     return bad
+
+
+def table_rule(n, amp=0.6):
+    """the deterministic table of tests/golden/make_golden.py:table_rule (value_i = frac(i * 2654435761 / 2^32)
+    - 0.5, times amp) — the G6 fixture was recorded with the hash tables filled this way"""
+    i = np.arange(n, dtype=np.uint64)
+    return (((i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)).astype(np.float64) / 4294967296.0 - 0.5).astype(
+        np.float32) * np.float32(amp)
+
+
+def g6_state(g, tag, n_xyz, n_rgb):
+    """state dict (numpy) of the model the G6 fixture was recorded with"""
+    state = {"xyz_encoder.params": table_rule(n_xyz), "rgb_encoder.params": table_rule(n_rgb)}
+    for k in ("xyz_net.0.weight", "xyz_net.0.bias", "xyz_net.2.weight", "xyz_net.2.bias", "rgb_net.params",
+              "norm_pred_header.params", "semantic_header.params"):
+        state[k] = g[f"{tag}_{k}"]
+    return state

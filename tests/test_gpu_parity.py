@@ -687,6 +687,40 @@ def test_field_forward_matches_oracle(ngp):
     assert torch.equal(n_pred, n_pred_t) and torch.equal(n_raw, n_raw_t) and torch.equal(sem, sem_t)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_field_matches_reference_ngp_golden(ngp, golden, tag):
+    """The HIP field against the outputs of the reference's OWN models/networks.py::NGP (G6 fixture:
+    forward, forward_test, density recorded on the CPU with a pure-torch tinycudann stand-in and
+    the hash tables filled by helpers.table_rule).  a: scale 0.5; b: scale 8 + appearance codes."""
+    from helpers import g6_state
+    g = golden("g6_ngp_field.npz")
+    scale = float(g[f"{tag}_scale"])
+    embed = f"{tag}_embedding_a" in g.files
+    model = ngp.networks.NGP(scale=scale, embed_a=embed, embed_a_len=8).to(DEV)
+    state = g6_state(g, tag, model.xyz_encoder.params.numel(), model.rgb_encoder.params.numel())
+    with torch.no_grad():
+        for k, v in state.items():
+            dict(model.named_parameters())[k].copy_(T(v))
+    kw = {"embedding_a": T(g[f"{tag}_embedding_a"])} if embed else {}
+    x, d = T(g[f"{tag}_x"]), T(g[f"{tag}_d"])
+    with torch.no_grad():
+        sig, rgb, n_raw, n_pred, sem = model(x, d, **kw)
+        sig_t, rgb_t, n_pred_t, n_raw_t, sem_t = model.forward_test(x, d, **kw)
+        dens = model.density(x)
+    close(N(sig), g[f"{tag}_fwd_sigmas"], 2e-4, 1e-5)
+    close(N(dens), g[f"{tag}_density"], 2e-4, 1e-5)
+    close(N(rgb), g[f"{tag}_fwd_rgbs"], 2e-4, 1e-5)
+    close(N(n_pred), g[f"{tag}_fwd_normals_pred"], 1e-3, 1e-4)
+    close(N(sem), g[f"{tag}_fwd_semantic"], 2e-4, 1e-5)
+    cos = (N(n_raw) * g[f"{tag}_fwd_normals_raw"]).sum(-1)
+    assert np.percentile(cos, 2) > 0.9995
+    close(N(sig_t), g[f"{tag}_test_sigmas"], 2e-4, 1e-5)
+    close(N(rgb_t), g[f"{tag}_test_rgbs"], 2e-4, 1e-5)
+    close(N(n_pred_t), g[f"{tag}_test_normals_pred"], 1e-3, 1e-4)
+    close(N(sem_t), g[f"{tag}_test_semantic"], 2e-4, 1e-5)
+    assert np.percentile((N(n_raw_t) * g[f"{tag}_test_normals_raw"]).sum(-1), 2) > 0.9995
+
+
 @pytest.mark.parametrize("scale", [8.0, 16.0])
 def test_field_forward_matches_oracle_unbounded(ngp, scale):
     """BASELINE configs 2/3 (Playground-like scale 8 with appearance codes, bicycle-like scale 16):

@@ -129,3 +129,32 @@ def test_g5_raymarcher_backward_segments(golden):
     indptr = np.concatenate([rays_a[:, 1], rays_a[-1:, 1] + rays_a[-1:, 2]])
     close(oracle.segment_csr_sum(g["dL_dxyzs"], indptr), g["dL_drays_o"])
     close(oracle.segment_csr_sum(g["dL_dxyzs"] * ts[:, None] + g["dL_ddirs"], indptr), g["dL_drays_d"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g6_field_wiring_matches_reference_ngp(golden, tag):
+    """oracle/field.py (the CPU field every GPU field test is checked against) vs the outputs of the
+    reference's OWN models/networks.py::NGP.forward / forward_test / density, recorded by
+    tests/golden/make_golden.py:g6_ngp_field with a pure-torch tinycudann stand-in: the Python wiring of
+    the field (normalisation, autograd normals, head inputs, column order, activations) is the
+    reference's.  a: scale 0.5; b: scale 8 with appearance codes (160-wide padded rgb_net input)."""
+    from helpers import g6_state
+    from oracle.field import CpuNGP
+    g = golden("g6_ngp_field.npz")
+    scale = float(g[f"{tag}_scale"])
+    b = float(np.exp(np.log(2048 * scale / 16) / 15))
+    _, n_xyz = oracle.grid_layout(16, 8, 19, 16, b)
+    _, n_rgb = oracle.grid_layout(16, 8, 21, 16, b)
+    field = CpuNGP(g6_state(g, tag, n_xyz, n_rgb), scale=scale)
+    emb = g[f"{tag}_embedding_a"] if f"{tag}_embedding_a" in g.files else None
+    sig, rgb, n_raw, n_pred, sem, _ = field(g[f"{tag}_x"], g[f"{tag}_d"], emb)
+    close(sig, g[f"{tag}_fwd_sigmas"], rtol=2e-4, atol=1e-5)
+    close(sig, g[f"{tag}_density"], rtol=2e-4, atol=1e-5)
+    close(rgb, g[f"{tag}_fwd_rgbs"], rtol=2e-4, atol=1e-5)
+    close(n_pred, g[f"{tag}_fwd_normals_pred"], rtol=1e-3, atol=1e-4)
+    close(sem, g[f"{tag}_fwd_semantic"], rtol=2e-4, atol=1e-5)
+    cos = (n_raw * g[f"{tag}_fwd_normals_raw"]).sum(-1)       # unit normals from d(sigma)/dx: same direction
+    assert np.percentile(cos, 2) > 0.9995, np.percentile(cos, 2)
+    # forward_test returns the same quantities with the two normal maps swapped (networks.py:282)
+    close(g[f"{tag}_test_normals_pred"], g[f"{tag}_fwd_normals_pred"], rtol=0, atol=0)
+    close(g[f"{tag}_test_normals_raw"], g[f"{tag}_fwd_normals_raw"], rtol=1e-5, atol=1e-6)
