@@ -9,6 +9,12 @@ Runs only in the build container (needs /root/reference); the GPU box uses the c
 `RayAABBIntersector` (a vren call) is replaced by a pure-torch slab test for the
 rendering_noCUDA.render case; its outputs are stored in the fixture as inputs.
 
+G6 / G7 go further and run the reference's own NGP class and render() on the CPU: `tinycudann` is
+the pure-torch stand-in tcnn_cpu_shim.py (asserted equal to the C oracle's encoder), `vren` is
+filled with the C oracle's restatements (install_oracle_vren), so the fixtures pin the reference's
+PYTHON wiring of the field and of the renderer; the primitives themselves are pinned separately
+(known-answer tests of the oracle, bit / tolerance parity of the HIP kernels against it).
+
 Fixtures hold numbers only (inputs and the reference's outputs).  Seed 20220806 = the
 reference's own seed (train.py:402).
 """
@@ -259,6 +265,107 @@ def g6_ngp_field():
     npz("g6_ngp_field.npz", **cases)
 
 
+def install_oracle_vren(oracle):
+    """fills the (so far empty) stand-in `vren` module with the CPU oracle's restatements, in the
+    reference's calling convention (torch tensors in / out, in-place updates where the CUDA extension
+    updates in place), so that the reference's own models/rendering.py can run on the CPU"""
+    v = sys.modules["vren"]
+    T = torch.from_numpy
+    A = lambda t: t.detach().contiguous().numpy()
+
+    def ray_aabb_intersect(o, d, c, h, max_hits):
+        return [T(x) for x in oracle.ray_aabb_intersect(A(o), A(d), A(c), A(h), max_hits)]
+
+    def raymarching_train(o, d, hits_t, bits, cascades, scale, esf, noise, G, max_samples):
+        return [T(x) for x in oracle.raymarching_train(A(o), A(d), A(hits_t), A(bits), cascades, scale, esf, A(noise),
+                                                       G, max_samples)]
+
+    def raymarching_test(o, d, hits_t, alive, bits, cascades, scale, esf, G, max_samples, n_samples):
+        assert hits_t.is_contiguous()
+        return [T(x) for x in oracle.raymarching_test(A(o), A(d), hits_t.numpy(), A(alive), A(bits), cascades, scale,
+                                                      esf, G, max_samples, n_samples)]
+
+    def composite_train_fw(sig, rgbs, nrm, sems, deltas, ts, rays_a, thr, classes):
+        return [T(x) for x in oracle.composite_train_fw(A(sig), A(rgbs), A(nrm), A(sems), A(deltas), A(ts), A(rays_a),
+                                                        thr, classes)]
+
+    def composite_test_fw(sig, rgbs, nrm, nrm_raw, sems, deltas, ts, hits_t, alive, thr, classes, n_eff, opacity, depth,
+                          rgb, normal, normal_raw, sem):
+        for t in (alive, opacity, depth, rgb, normal, normal_raw, sem):
+            assert t.is_contiguous()
+        oracle.composite_test_fw(A(sig), A(rgbs), A(nrm), A(nrm_raw), A(sems), A(deltas), A(ts), A(hits_t), alive.numpy(),
+                                 thr, classes, A(n_eff), opacity.numpy(), depth.numpy(), rgb.numpy(), normal.numpy(),
+                                 normal_raw.numpy(), sem.numpy())
+
+    def composite_refloss_fw(sig, ndiff, nori, deltas, ts, rays_a, thr):
+        return [T(x) for x in oracle.composite_refloss_fw(A(sig), A(ndiff), A(nori), A(deltas), A(ts), A(rays_a), thr)]
+
+    for f in (ray_aabb_intersect, raymarching_train, raymarching_test, composite_train_fw, composite_test_fw,
+              composite_refloss_fw):
+        setattr(v, f.__name__, f)
+
+
+def g7_render_paths():
+    """The reference's OWN models/rendering.py::render — train path and test path — run on the CPU:
+    the field is the reference's NGP class on the pure-torch tinycudann stand-in (as in G6), the vren
+    entry points are the C oracle's restatements (each of them bit-checked against the HIP kernels
+    by the GPU tests).  Pins the PYTHON glue of the renderer: AABB + near clamp, marcher call and
+    trimming, per-sample kwargs, compositor call, background, RefLoss inputs, and at test time the
+    whole progressive loop (samples per round, alive list, in-place hits_t, normalisation, argmax)."""
+    sys.path.insert(0, OUT)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import tcnn_cpu_shim
+    import oracle
+    sys.modules["tinycudann"] = tcnn_cpu_shim
+    install_oracle_vren(oracle)
+    from models import networks as ref_net
+    from models import rendering as ref_render
+    torch.manual_seed(SEED + 8)
+    g = np.random.default_rng(SEED + 9)
+    model = ref_net.NGP(scale=0.5)
+    cases = {}
+    with torch.no_grad():
+        model.xyz_encoder.params.copy_(torch.from_numpy(table_rule(model.xyz_encoder.params.numel())))
+        model.rgb_encoder.params.copy_(torch.from_numpy(table_rule(model.rgb_encoder.params.numel())))
+        for name, p in model.named_parameters():
+            if name.startswith("xyz_net") or name in ("rgb_net.params", "norm_pred_header.params",
+                                                      "semantic_header.params"):
+                p.copy_(torch.from_numpy((g.standard_normal(p.shape) * 0.15).astype(np.float32)))
+                if name == "xyz_net.2.bias":
+                    p.fill_(30.0)       # dense medium: rays saturate and terminate inside the occupied ball
+                cases[name] = p.detach().clone()
+        # occupancy: a ball of radius 0.3 plus a slab, packed through morton order like update_density_grid does
+        G = model.grid_size
+        c = np.stack(np.meshgrid(*[np.arange(G, dtype=np.int32)] * 3, indexing="ij"), -1).reshape(-1, 3)
+        xyz = (c.astype(np.float32) + 0.5) / G - 0.5
+        occ = ((xyz ** 2).sum(-1) < 0.3 ** 2) | ((np.abs(xyz[:, 2] + 0.38) < 0.03) & (np.abs(xyz[:, 0]) < 0.4))
+        grid = np.zeros(G ** 3, np.float32)
+        grid[oracle.morton3D(c)] = occ.astype(np.float32)
+        bits = oracle.packbits(grid, 0.5)
+        model.density_bitfield.copy_(torch.from_numpy(bits))
+    cases["density_bitfield"] = bits
+    n = 64
+    o = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1) * 1.5
+    tgt = (torch.rand(n, 3) - 0.5) * 0.9
+    tgt[-6:] = torch.tensor([3.0, 3.0, 3.0])          # a few rays that miss the box
+    d = torch.nn.functional.normalize(tgt - o, dim=-1)
+    noise = torch.rand(n)
+    cases["rays_o"], cases["rays_d"], cases["noise"] = o, d, noise
+    real_rand_like = torch.rand_like
+    torch.rand_like = lambda t, *a, **k: noise.clone()   # the one random draw of the train path (custom_functions.py:84)
+    try:
+        res = ref_render.render(model, o, d, exp_step_factor=0.0, num_classes=7)
+    finally:
+        torch.rand_like = real_rand_like
+    for k, v in res.items():
+        cases["train_" + k] = v.detach() if torch.is_tensor(v) else np.asarray(v)
+    with torch.no_grad():
+        res = ref_render.render(model, o, d, test_time=True, exp_step_factor=0.0, num_classes=7, T_threshold=1e-2)
+    for k, v in res.items():
+        cases["test_" + k] = v.detach() if torch.is_tensor(v) else np.asarray(v)
+    npz("g7_render_paths.npz", **cases)
+
+
 if __name__ == "__main__":
     cf, rn = import_reference()
     g1_raw2outputs(cf)
@@ -267,3 +374,4 @@ if __name__ == "__main__":
     g4_activations(cf)
     g5_raymarcher_bw(cf)
     g6_ngp_field()
+    g7_render_paths()

@@ -1078,6 +1078,64 @@ def test_render_with_no_samples(ngp):
     assert torch.equal(test["rgb"], ref["rgb"]) and torch.equal(test["opacity"], ref["opacity"])
 
 
+def test_render_matches_reference_render_golden(ngp, golden, monkeypatch):
+    """render() — train path and test path — against the G7 fixture: the reference's OWN
+    models/rendering.py::render run on the CPU (field = the reference's NGP class on the pure-torch
+    tinycudann stand-in, vren = the C oracle).  Same rays, same occupancy bitfield, same marcher noise."""
+    from helpers import table_rule
+    from ngp_amd.rendering import render
+    g = golden("g7_render_paths.npz")
+    model = ngp.networks.NGP(scale=0.5).to(DEV)
+    with torch.no_grad():
+        model.xyz_encoder.params.copy_(T(table_rule(model.xyz_encoder.params.numel())))
+        model.rgb_encoder.params.copy_(T(table_rule(model.rgb_encoder.params.numel())))
+        named = dict(model.named_parameters())
+        for k in ("xyz_net.0.weight", "xyz_net.0.bias", "xyz_net.2.weight", "xyz_net.2.bias", "rgb_net.params",
+                  "norm_pred_header.params", "semantic_header.params"):
+            named[k].copy_(T(g[k]))
+        model.density_bitfield.copy_(T(g["density_bitfield"]))
+    o, d = T(g["rays_o"]), T(g["rays_d"])
+    noise = T(g["noise"])
+    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: noise.clone())   # the marcher's jitter draw
+    with torch.no_grad():
+        res = render(model, o, d, exp_step_factor=0.0, num_classes=7)
+    monkeypatch.undo()
+    # marching: exact
+    assert int(res["total_samples"]) == int(g["train_total_samples"])
+    assert np.array_equal(N(res["rays_a"]), g["train_rays_a"])
+    assert np.array_equal(N(res["ts"]), g["train_ts"]) and np.array_equal(N(res["deltas"]), g["train_deltas"])
+    assert np.array_equal(N(res["xyzs"]), g["train_xyzs"])
+    close(N(res["sigma"]), g["train_sigma"], 2e-4, 1e-5)
+    # compositing: rays whose transmittance passes within 1e-4 (relative) of the threshold may stop one
+    # sample earlier / later under the parallel scan; everything else to fp32 tolerance
+    bad = borderline_rays(g["train_sigma"], g["train_deltas"], g["train_rays_a"], 1e-4)
+    keep = ~bad
+    assert keep.sum() >= 0.9 * len(keep)
+    for k, tol in (("opacity", 2e-5), ("depth", 1e-4), ("rgb", 1e-4), ("normal_pred", 1e-3), ("semantic", 1e-4),
+                   ("Ro", 2e-3), ("Rp", 2e-3)):
+        close(N(res[k])[keep], g["train_" + k][keep], 2e-3 if k in ("Ro", "Rp") else 5e-4, tol)
+    smask = np.zeros(len(g["train_ws"]), bool)
+    for r, st, c in g["train_rays_a"]:
+        if keep[r]:
+            smask[st:st + c] = True
+    close(N(res["ws"])[smask], g["train_ws"][smask], 5e-4, 1e-6)
+    assert abs(int(res["vr_samples"]) - int(g["train_vr_samples"])) <= int(bad.sum()) + 1
+    # test-time path
+    with torch.no_grad():
+        for ref_loop in (False, True):
+            tst = render(model, o, d, test_time=True, exp_step_factor=0.0, num_classes=7, T_threshold=1e-2,
+                         reference_test_loop=ref_loop)
+            assert abs(int(tst["total_samples"]) - int(g["test_total_samples"])) <= 0.01 * int(g["test_total_samples"])
+            close(N(tst["opacity"]), g["test_opacity"], 2e-3, 2e-4)
+            hit = g["test_opacity"] > 0.5
+            close(N(tst["depth"])[hit], g["test_depth"][hit], 2e-3, 2e-4)
+            close(N(tst["rgb"]), g["test_rgb"], 2e-3, 3e-4)
+            close(N(tst["points"])[hit], g["test_points"][hit], 2e-3, 3e-4)
+            assert ((N(tst["normal_pred"]) * g["test_normal_pred"]).sum(-1)[hit] > 0.999).all()
+            assert np.percentile((N(tst["normal_raw"]) * g["test_normal_raw"]).sum(-1)[hit], 5) > 0.999
+            assert (N(tst["semantic"])[hit] == g["test_semantic"][hit]).mean() > 0.97
+
+
 def test_differentiable_normals_h4(ngp):
     """--normal_ref path: a loss on normals_raw reaches the density table through the grid's double
     backward; checked against a central difference along a random direction in parameter space."""
