@@ -300,8 +300,24 @@ def install_oracle_vren(oracle):
     def composite_refloss_fw(sig, ndiff, nori, deltas, ts, rays_a, thr):
         return [T(x) for x in oracle.composite_refloss_fw(A(sig), A(ndiff), A(nori), A(deltas), A(ts), A(rays_a), thr)]
 
+    def composite_train_bw(dO, dD, dRGB, dN, dS, dWs, sig, rgbs, nrm, ws, deltas, ts, rays_a, opacity, depth, rgb, normal,
+                           thr, classes):
+        return [T(x) for x in oracle.composite_train_bw(A(dO), A(dD), A(dRGB), A(dN), A(dS), A(dWs), A(sig), A(rgbs),
+                                                        A(nrm), A(ws), A(deltas), A(ts), A(rays_a), A(opacity), A(depth),
+                                                        A(rgb), A(normal), thr, classes)]
+
+    def composite_refloss_bw(dLo, dLp, sig, ndiff, nori, deltas, ts, rays_a, lo, lp, thr):
+        return [T(x) for x in oracle.composite_refloss_bw(A(dLo), A(dLp), A(sig), A(ndiff), A(nori), A(deltas), A(ts),
+                                                          A(rays_a), A(lo), A(lp), thr)]
+
+    def distortion_loss_fw(ws, deltas, ts, rays_a):
+        return [T(x) for x in oracle.distortion_loss_fw(A(ws), A(deltas), A(ts), A(rays_a))]
+
+    def distortion_loss_bw(dL, wi, wti, ws, deltas, ts, rays_a):
+        return T(oracle.distortion_loss_bw(A(dL), A(wi), A(wti), A(ws), A(deltas), A(ts), A(rays_a)))
+
     for f in (ray_aabb_intersect, raymarching_train, raymarching_test, composite_train_fw, composite_test_fw,
-              composite_refloss_fw):
+              composite_refloss_fw, composite_train_bw, composite_refloss_bw, distortion_loss_fw, distortion_loss_bw):
         setattr(v, f.__name__, f)
 
 
@@ -364,6 +380,49 @@ def g7_render_paths():
     for k, v in res.items():
         cases["test_" + k] = v.detach() if torch.is_tensor(v) else np.asarray(v)
     npz("g7_render_paths.npz", **cases)
+
+    # ---- G8: one whole training step of the reference: render -> NeRFLoss (losses.py) -> sum of term
+    # means (train.py:307) -> backward through the reference's autograd Functions -> gradient clipping at
+    # 50 -> torch.optim.Adam(lr, eps=1e-8) (train.py:244,435).  Same model / rays / noise as G7.
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_losses", REF + "/losses.py")
+    ref_losses = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_losses)
+    step = {k: v for k, v in cases.items() if not (k.startswith("train_") or k.startswith("test_"))}
+    gt = torch.rand(n, 3)
+    step["rgb_gt"] = gt
+    torch.rand_like = lambda t, *a, **k: noise.clone()
+    try:
+        res = ref_render.render(model, o, d, exp_step_factor=0.0, num_classes=7)
+    finally:
+        torch.rand_like = real_rand_like
+    loss_d = ref_losses.NeRFLoss()(res, {"rgb": gt})
+    loss = sum(lo.mean() for lo in loss_d.values())
+    for k, v in loss_d.items():
+        step["loss_" + k] = v.mean().detach()
+    step["loss"] = loss.detach()
+    loss.backward()
+    small = ("xyz_net.0.weight", "xyz_net.0.bias", "xyz_net.2.weight", "xyz_net.2.bias", "rgb_net.params",
+             "norm_pred_header.params", "semantic_header.params")
+    named = dict(model.named_parameters())
+    for k in small:
+        step["grad_" + k] = named[k].grad.clone()
+    for k in ("xyz_encoder.params", "rgb_encoder.params"):
+        gr = named[k].grad.numpy()
+        idx = np.argpartition(np.abs(gr), -4096)[-4096:]            # the 4096 largest entries ...
+        idx = np.concatenate([idx, (np.arange(4096, dtype=np.int64) * 7919) % gr.size])   # ... and 4096 fixed ones
+        step["grad_idx_" + k], step["grad_val_" + k] = idx, gr[idx]
+        step["grad_l2_" + k], step["grad_l1_" + k] = np.float64(np.sqrt((gr.astype(np.float64) ** 2).sum())), np.float64(
+            np.abs(gr).sum(dtype=np.float64))
+    params = [p for p in model.parameters()]
+    step["grad_norm"] = torch.nn.utils.clip_grad_norm_(params, 50.0)
+    opt = torch.optim.Adam(params, 1e-2, eps=1e-8)
+    opt.step()
+    for k in small:
+        step["new_" + k] = named[k].detach().clone()
+    for k in ("xyz_encoder.params", "rgb_encoder.params"):
+        step["new_val_" + k] = named[k].detach().numpy()[step["grad_idx_" + k]]
+    npz("g8_train_step.npz", **step)
 
 
 if __name__ == "__main__":

@@ -1136,6 +1136,81 @@ def test_render_matches_reference_render_golden(ngp, golden, monkeypatch):
             assert (N(tst["semantic"])[hit] == g["test_semantic"][hit]).mean() > 0.97
 
 
+def test_training_step_matches_reference_golden(ngp, golden, monkeypatch):
+    """One whole training step against the G8 fixture — the reference's OWN render() -> NeRFLoss
+    (losses.py) -> sum of term means -> backward through its autograd Functions -> clip_grad_norm_(50)
+    -> torch.optim.Adam(lr=1e-2, eps=1e-8).step(), run on the CPU (tinycudann = pure-torch stand-in,
+    vren = C oracle).  Here: render() -> fused loss kernels -> backward -> NGPTrainer.optimizer_step()."""
+    from helpers import table_rule
+    from ngp_amd.losses import nerf_loss_and_grads
+    from ngp_amd.rendering import render
+    from ngp_amd.trainer import NGPTrainer
+    g = golden("g8_train_step.npz")
+    small = ("xyz_net.0.weight", "xyz_net.0.bias", "xyz_net.2.weight", "xyz_net.2.bias", "rgb_net.params",
+             "norm_pred_header.params", "semantic_header.params")
+    tables = ("xyz_encoder.params", "rgb_encoder.params")
+    model = ngp.networks.NGP(scale=0.5).to(DEV)
+    with torch.no_grad():
+        model.xyz_encoder.params.copy_(T(table_rule(model.xyz_encoder.params.numel())))
+        model.rgb_encoder.params.copy_(T(table_rule(model.rgb_encoder.params.numel())))
+        named = dict(model.named_parameters())
+        for k in small:
+            named[k].copy_(T(g[k]))
+        model.density_bitfield.copy_(T(g["density_bitfield"]))
+    tr = NGPTrainer(model, lr=1e-2)                 # flat parameter / gradient / Adam-state buffers
+    named = dict(model.named_parameters())
+    o, d, gt = T(g["rays_o"]), T(g["rays_d"]), T(g["rgb_gt"])
+    noise = T(g["noise"])
+    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: noise.clone())
+    res = render(model, o, d, exp_step_factor=0.0, num_classes=7)
+    monkeypatch.undo()
+    terms, (d_rgb, d_op, d_ws) = nerf_loss_and_grads(res["rgb"], res["opacity"], res["ws"], res["deltas"], res["ts"],
+                                                    res["rays_a"], gt, tr.loss_fn.lambda_opa, tr.loss_fn.lambda_distortion)
+    terms = N(terms)
+    for i, k in enumerate(("loss", "loss_rgb", "loss_opacity", "loss_distortion")):
+        assert abs(terms[i] - float(g[k])) <= 2e-4 * abs(float(g[k])) + 1e-9, (k, terms[i], float(g[k]))
+    torch.autograd.backward([res["rgb"], res["opacity"], res["ws"]], [d_rgb, d_op, d_ws])
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+    for k in small:
+        ref = g["grad_" + k]
+        mine = N(named[k].grad) if named[k].grad is not None else np.zeros_like(ref)
+        if np.abs(ref).max() == 0:                       # headers: the reference back-propagates exact zeros
+            assert not mine.any(), k
+        else:
+            assert rel(mine, ref) < 3e-3, (k, rel(mine, ref))
+    for k in tables:
+        idx = g["grad_idx_" + k]
+        mine = N(named[k].grad)
+        assert rel(mine[idx], g["grad_val_" + k]) < 3e-3, k
+        assert abs(np.sqrt((mine.astype(np.float64) ** 2).sum()) - float(g["grad_l2_" + k])) < 3e-3 * float(g["grad_l2_" + k])
+        assert abs(np.abs(mine).sum(dtype=np.float64) - float(g["grad_l1_" + k])) < 3e-3 * float(g["grad_l1_" + k])
+    mine_grads = {k: N(named[k].grad).copy() for k in tables}
+    # clip + Adam
+    tr.optimizer_step()
+    tr.wait()
+    torch.cuda.synchronize()
+    assert float(g["grad_norm"]) < 50.0                   # no clipping on this step; the norm itself:
+    lr = 1e-2
+    for k in small:
+        ref_new, ref_g, old = g["new_" + k], g["grad_" + k], g[k]
+        mine_new = N(named[k])
+        big = np.abs(ref_g) > 3e-7                        # first Adam step: p -= lr * g / (|g| + eps)
+        assert not big.any() or np.abs(mine_new[big] - ref_new[big]).max() < 2e-3 * lr, k
+        zero = ref_g == 0
+        assert np.array_equal(mine_new[zero], old[zero]), k
+    for k in tables:
+        idx = g["grad_idx_" + k]
+        ref_g, ref_new = g["grad_val_" + k], g["new_val_" + k]
+        mine_new = N(named[k])[idx]
+        big = np.abs(ref_g) > 3e-7        # |g| >> eps: the step is lr * g / (|g| + 1e-8), insensitive to 0.3 % of g
+        assert big.sum() > 500 and np.abs(mine_new[big] - ref_new[big]).max() < 2e-3 * lr, (k, int(big.sum()))
+        zero = (ref_g == 0) & (mine_grads[k][idx] == 0)
+        assert zero.sum() > 1000 and np.array_equal(mine_new[zero], ref_new[zero]), k
+
+
 def test_differentiable_normals_h4(ngp):
     """--normal_ref path: a loss on normals_raw reaches the density table through the grid's double
     backward; checked against a central difference along a random direction in parameter space."""
