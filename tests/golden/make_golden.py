@@ -425,6 +425,64 @@ def g7_render_paths():
     npz("g8_train_step.npz", **step)
 
 
+def noise_rule(shape, call_index):
+    """deterministic stand-in for torch.rand_like in update_density_grid: u_i = frac((i + 1 + 7919 call) * phi)"""
+    n = int(np.prod(shape))
+    i = np.arange(1, n + 1, dtype=np.float64) + 7919.0 * call_index
+    return torch.from_numpy(np.mod(i * 0.6180339887498949, 1.0).astype(np.float32).reshape(shape))
+
+
+def g9_density_grid_update():
+    """The reference's OWN NGP.update_density_grid (networks.py:379-408, warm-up branch: every cell) run
+    twice on the CPU — cell centres, jitter, density(), EMA with decay, mean threshold, packbits in
+    morton order (vren.morton3D / packbits = the C oracle).  The jitter draws are replaced by
+    noise_rule so that the GPU test can feed the same numbers."""
+    sys.path.insert(0, OUT)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import tcnn_cpu_shim
+    import oracle
+    sys.modules["tinycudann"] = tcnn_cpu_shim
+    v = sys.modules["vren"]
+    v.morton3D = lambda c: torch.from_numpy(oracle.morton3D(c.numpy()))
+    v.morton3D_invert = lambda i: torch.from_numpy(oracle.morton3D_invert(i.numpy()))
+
+    def packbits(grid, thr, bitfield):
+        bitfield.copy_(torch.from_numpy(oracle.packbits(grid.detach().contiguous().numpy().reshape(-1), float(thr))))
+    v.packbits = packbits
+    from models import networks as ref_net
+    torch.manual_seed(SEED + 10)
+    g = np.random.default_rng(SEED + 11)
+    model = ref_net.NGP(scale=0.5)
+    cases = {}
+    with torch.no_grad():
+        model.xyz_encoder.params.copy_(torch.from_numpy(table_rule(model.xyz_encoder.params.numel())))
+        for name, p in model.named_parameters():
+            if name.startswith("xyz_net"):
+                p.copy_(torch.from_numpy((g.standard_normal(p.shape) * 0.15).astype(np.float32)))
+                if name == "xyz_net.2.bias":
+                    p.fill_(2.0)
+                cases[name] = p.detach().clone()
+    G = model.grid_size
+    model.register_buffer("density_grid", torch.zeros(model.cascades, G ** 3))
+    model.register_buffer("grid_coords", torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32)] * 3,
+                                                                    indexing="ij"), -1).reshape(-1, 3))
+    real = torch.rand_like
+    thr = 0.01 * 1024 / 3 ** 0.5
+    try:
+        for call in range(2):
+            torch.rand_like = lambda t, *a, _c=call, **k: noise_rule(tuple(t.shape), _c)
+            with torch.no_grad():
+                model.update_density_grid(thr, warmup=True)
+            dg = model.density_grid.numpy()
+            cases[f"u{call}_grid_sub"] = dg[:, ::257].copy()
+            cases[f"u{call}_mean_pos"] = np.float64(dg[dg > 0].mean())
+            cases[f"u{call}_bitfield"] = model.density_bitfield.numpy().copy()
+    finally:
+        torch.rand_like = real
+    cases["density_threshold"] = np.float64(thr)
+    npz("g9_density_grid_update.npz", **cases)
+
+
 if __name__ == "__main__":
     cf, rn = import_reference()
     g1_raw2outputs(cf)
@@ -434,3 +492,4 @@ if __name__ == "__main__":
     g5_raymarcher_bw(cf)
     g6_ngp_field()
     g7_render_paths()
+    g9_density_grid_update()

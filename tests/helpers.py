@@ -75,3 +75,10 @@ def g6_state(g, tag, n_xyz, n_rgb):
               "norm_pred_header.params", "semantic_header.params"):
         state[k] = g[f"{tag}_{k}"]
     return state
+
+
+def noise_rule(shape, call_index):
+    """tests/golden/make_golden.py:noise_rule — the jitter draws the G9 fixture was recorded with"""
+    n = int(np.prod(shape))
+    i = np.arange(1, n + 1, dtype=np.float64) + 7919.0 * call_index
+    return np.mod(i * 0.6180339887498949, 1.0).astype(np.float32).reshape(shape)

@@ -1211,6 +1211,44 @@ def test_training_step_matches_reference_golden(ngp, golden, monkeypatch):
         assert zero.sum() > 1000 and np.array_equal(mine_new[zero], ref_new[zero]), k
 
 
+def test_density_grid_update_matches_reference_golden(ngp, golden, monkeypatch):
+    """NGP.update_density_grid (warm-up branch, twice) against the G9 fixture: the reference's OWN
+    method run on the CPU with the same jitter numbers.  Cell centres + jitter (ngp_grid_cell_points),
+    density(), EMA with decay (ngp_density_grid_ema), mean threshold kept on the device, packbits."""
+    from helpers import noise_rule, table_rule
+    g = golden("g9_density_grid_update.npz")
+    model = ngp.networks.NGP(scale=0.5).to(DEV)
+    G = model.grid_size
+    model.register_buffer("density_grid", torch.zeros(model.cascades, G ** 3, device=DEV))
+    coords = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=DEV)] * 3, indexing="ij"), -1)
+    model.register_buffer("grid_coords", coords.reshape(-1, 3).contiguous())
+    with torch.no_grad():
+        model.xyz_encoder.params.copy_(T(table_rule(model.xyz_encoder.params.numel())))
+        named = dict(model.named_parameters())
+        for k in ("xyz_net.0.weight", "xyz_net.0.bias", "xyz_net.2.weight", "xyz_net.2.bias"):
+            named[k].copy_(T(g[k]))
+    thr = float(g["density_threshold"])
+    real_rand = torch.rand
+    for call in range(2):
+        def fake_rand(*size, **kw):
+            shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+            if shape == (G ** 3, 3):
+                return T(noise_rule(shape, call))
+            return real_rand(*size, **kw)
+        monkeypatch.setattr(torch, "rand", fake_rand)
+        with torch.no_grad():
+            model.update_density_grid(thr, warmup=True)
+        monkeypatch.undo()
+        dg = N(model.density_grid)
+        close(dg[:, ::257], g[f"u{call}_grid_sub"], 2e-4, 1e-5)
+        assert abs(dg[dg > 0].mean() - float(g[f"u{call}_mean_pos"])) < 1e-4
+        mine = np.unpackbits(N(model.density_bitfield))
+        ref = np.unpackbits(g[f"u{call}_bitfield"])
+        # a cell whose density is within fp32 noise of the mean threshold may fall on either side
+        assert (mine != ref).mean() < 2e-3, (mine != ref).mean()
+        assert abs(mine.mean() - ref.mean()) < 2e-3
+
+
 def test_differentiable_normals_h4(ngp):
     """--normal_ref path: a loss on normals_raw reaches the density table through the grid's double
     backward; checked against a central difference along a random direction in parameter space."""
