@@ -424,6 +424,36 @@ def g7_render_paths():
         step["new_val_" + k] = named[k].detach().numpy()[step["grad_idx_" + k]]
     npz("g8_train_step.npz", **step)
 
+    # ---- G10: the --normal_ref recipe (losses.py:107-109): Ro / Rp enter the loss, so the gradient runs
+    # through RefLoss.backward and through normals_raw = -normalize(d sigma / dx), i.e. through the
+    # DOUBLE backward of the density encoder and MLP (networks.py:186-196, create_graph=True)
+    model.zero_grad(set_to_none=True)
+    with torch.no_grad():     # back to the parameters the fixture documents (the Adam step above moved them)
+        model.xyz_encoder.params.copy_(torch.from_numpy(table_rule(model.xyz_encoder.params.numel())))
+        model.rgb_encoder.params.copy_(torch.from_numpy(table_rule(model.rgb_encoder.params.numel())))
+        for k in small:
+            named[k].copy_(step[k])
+    ref = {k: step[k] for k in small + ("density_bitfield", "rays_o", "rays_d", "noise", "rgb_gt")}
+    torch.rand_like = lambda t, *a, **k: noise.clone()
+    try:
+        res = ref_render.render(model, o, d, exp_step_factor=0.0, num_classes=7)
+    finally:
+        torch.rand_like = real_rand_like
+    loss_d = ref_losses.NeRFLoss()(res, {"rgb": gt}, normal_ref=True)
+    loss = sum(lo.mean() for lo in loss_d.values())
+    for k, v in loss_d.items():
+        ref["loss_" + k] = v.mean().detach()
+    ref["loss"] = loss.detach()
+    loss.backward()
+    for k in small:
+        ref["grad_" + k] = named[k].grad.clone()
+    for k in ("xyz_encoder.params", "rgb_encoder.params"):
+        gr = named[k].grad.numpy()
+        idx = np.argpartition(np.abs(gr), -4096)[-4096:]
+        ref["grad_idx_" + k], ref["grad_val_" + k] = idx, gr[idx]
+        ref["grad_l2_" + k] = np.float64(np.sqrt((gr.astype(np.float64) ** 2).sum()))
+    npz("g10_normal_ref_step.npz", **ref)
+
 
 def noise_rule(shape, call_index):
     """deterministic stand-in for torch.rand_like in update_density_grid: u_i = frac((i + 1 + 7919 call) * phi)"""

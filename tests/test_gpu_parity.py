@@ -1249,6 +1249,54 @@ def test_density_grid_update_matches_reference_golden(ngp, golden, monkeypatch):
         assert abs(mine.mean() - ref.mean()) < 2e-3
 
 
+def test_normal_ref_step_matches_reference_golden(ngp, golden, monkeypatch):
+    """The --normal_ref recipe against the G10 fixture (the reference's render + NeRFLoss(normal_ref=True)
+    + backward on the CPU): Ro / Rp are in the loss, the gradient reaches the density table and MLP
+    through RefLoss.backward and the DOUBLE backward of the field (model.differentiable_normals)."""
+    from helpers import table_rule
+    from ngp_amd.losses import NeRFLoss
+    from ngp_amd.rendering import render
+    g = golden("g10_normal_ref_step.npz")
+    small = ("xyz_net.0.weight", "xyz_net.0.bias", "xyz_net.2.weight", "xyz_net.2.bias", "rgb_net.params",
+             "norm_pred_header.params", "semantic_header.params")
+    model = ngp.networks.NGP(scale=0.5).to(DEV)
+    with torch.no_grad():
+        model.xyz_encoder.params.copy_(T(table_rule(model.xyz_encoder.params.numel())))
+        model.rgb_encoder.params.copy_(T(table_rule(model.rgb_encoder.params.numel())))
+        named = dict(model.named_parameters())
+        for k in small:
+            named[k].copy_(T(g[k]))
+        model.density_bitfield.copy_(T(g["density_bitfield"]))
+    model.differentiable_normals = True
+    o, d, gt = T(g["rays_o"]), T(g["rays_d"]), T(g["rgb_gt"])
+    noise = T(g["noise"])
+    monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: noise.clone())
+    res = render(model, o, d, exp_step_factor=0.0, num_classes=7)
+    monkeypatch.undo()
+    loss_d = NeRFLoss()(res, {"rgb": gt}, normal_ref=True)
+    assert set(loss_d) == {"rgb", "opacity", "distortion", "normal_ref_rp", "normal_ref_ro"}
+    for k, v in loss_d.items():
+        ref = float(g["loss_" + k])
+        assert abs(float(v.mean()) - ref) <= 1e-3 * abs(ref) + 1e-9, (k, float(v.mean()), ref)
+    loss = sum(v.mean() for v in loss_d.values())
+    loss.backward()
+
+    def rel(a, b):
+        return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+    for k in small:
+        ref = g["grad_" + k]
+        mine = N(named[k].grad) if named[k].grad is not None else np.zeros_like(ref)
+        if np.abs(ref).max() == 0:
+            assert not mine.any(), k
+        else:
+            assert rel(mine, ref) < 5e-3, (k, rel(mine, ref))
+    for k in ("xyz_encoder.params", "rgb_encoder.params"):
+        mine = N(named[k].grad)
+        assert rel(mine[g["grad_idx_" + k]], g["grad_val_" + k]) < 5e-3, k
+        l2 = float(g["grad_l2_" + k])
+        assert abs(np.sqrt((mine.astype(np.float64) ** 2).sum()) - l2) < 5e-3 * l2, k
+
+
 def test_differentiable_normals_h4(ngp):
     """--normal_ref path: a loss on normals_raw reaches the density table through the grid's double
     backward; checked against a central difference along a random direction in parameter space."""
