@@ -165,48 +165,42 @@ class TruncTanh(torch.autograd.Function):
 
 
 def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
-    """Hierarchical sampling (custom_functions.py:248-278)."""
-    weights = weights + 1e-5
-    pdf = weights / torch.sum(weights, -1, keepdim=True)
-    cdf = torch.cumsum(pdf, -1)
-    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    """Inverse-CDF (hierarchical) sampling of `N_samples` depths per ray from the piecewise-constant
+    density `weights` (.., n) over the bin edges `bins` (.., n+1); det=True uses evenly spaced
+    quantiles instead of uniform draws.  Same contract as custom_functions.py:248-278."""
+    w = weights + 1e-5                                             # no empty bins
+    cdf = torch.cumsum(w / w.sum(-1, keepdim=True), -1)
+    cdf = torch.nn.functional.pad(cdf, (1, 0))                     # (.., n+1), starts at 0
+    lead = list(cdf.shape[:-1])
     if det:
-        u = torch.linspace(0., 1., steps=N_samples, device=cdf.device)
-        u = u.expand(list(cdf.shape[:-1]) + [N_samples])
+        u = torch.linspace(0., 1., steps=N_samples, device=cdf.device).expand(lead + [N_samples])
     else:
-        u = torch.rand(list(cdf.shape[:-1]) + [N_samples], device=cdf.device)
-    u = u.contiguous()
-    inds = torch.searchsorted(cdf, u, right=True)
-    below = torch.clamp(inds - 1, min=0)
-    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
-    cdf_g0, cdf_g1 = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)
-    bins_g0, bins_g1 = torch.gather(bins, -1, below), torch.gather(bins, -1, above)
-    denom = cdf_g1 - cdf_g0
-    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
-    t = (u - cdf_g0) / denom
-    return bins_g0 + t * (bins_g1 - bins_g0)
+        u = torch.rand(lead + [N_samples], device=cdf.device)
+    hi = torch.searchsorted(cdf, u.contiguous(), right=True)       # first edge whose cdf exceeds u
+    lo = (hi - 1).clamp(min=0)
+    hi = hi.clamp(max=cdf.shape[-1] - 1)
+    c_lo, c_hi = cdf.gather(-1, lo), cdf.gather(-1, hi)
+    b_lo, b_hi = bins.gather(-1, lo), bins.gather(-1, hi)
+    span = c_hi - c_lo
+    span = torch.where(span < 1e-5, torch.ones_like(span), span)   # flat stretch: stay on the lower edge
+    return b_lo + (u - c_lo) / span * (b_hi - b_lo)
 
 
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, classes=7):
-    """Dense-sample compositing (custom_functions.py:280-321)."""
-    sigmas = raw[..., 0]
-    rgbs = raw[..., 1:4]
-    normals_raw = raw[..., 4:7]
-    normals_pred = raw[..., 7:10]
-    sems = raw[..., 10:]
-    dists = z_vals[..., 1:] - z_vals[..., :-1]
-    dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], -1)
-    dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
-    noise = 0.
+    """Compositing of S dense samples per ray (custom_functions.py:280-321).
+    raw (R, S, 10+classes) = [sigma | rgb 3 | normal_raw 3 | normal_pred 3 | semantic classes];
+    the last interval is 1e10 long, so any density on the last sample closes the ray.
+    -> opacity, rgb, normal_raw, normal_pred, semantic, weights (R,S), depth"""
+    sigma, feats = raw[..., 0], raw[..., 1:]
+    seg = torch.diff(z_vals, dim=-1)
+    seg = torch.cat([seg, seg.new_full(seg[..., :1].shape, 1e10)], -1) * rays_d.norm(dim=-1, keepdim=True)
     if raw_noise_std > 0.:
-        noise = torch.randn(sigmas.shape, device=raw.device) * raw_noise_std
-    alpha = 1. - torch.exp(-(sigmas + noise) * dists)
-    ones = torch.ones((alpha.shape[0], 1), device=raw.device)
-    weights = alpha * torch.cumprod(torch.cat([ones, 1. - alpha + 1e-10], -1), -1)[:, :-1]
-    opacity = torch.sum(weights, -1)
-    rgb_map = torch.sum(weights[..., None] * rgbs, -2)
-    normal_raw = torch.sum(weights[..., None] * normals_raw, -2)
-    normal_pred = torch.sum(weights[..., None] * normals_pred, -2)
-    sem = torch.sum(weights[..., None] * sems, -2)
-    depth_map = torch.sum(weights * z_vals, -1)
-    return opacity, rgb_map, normal_raw, normal_pred, sem, weights, depth_map
+        sigma = sigma + torch.randn_like(sigma) * raw_noise_std
+    alpha = 1. - torch.exp(-sigma * seg)
+    # transmittance in front of each sample: exclusive running product of (1 - alpha + 1e-10)
+    trans = torch.cumprod(torch.nn.functional.pad(1. - alpha + 1e-10, (1, 0), value=1.0), -1)[..., :-1]
+    weights = alpha * trans
+    mixed = (weights[..., None] * feats).sum(-2)                   # every per-sample feature, composited
+    opacity = weights.sum(-1)
+    depth_map = (weights * z_vals).sum(-1)
+    return opacity, mixed[..., 0:3], mixed[..., 3:6], mixed[..., 6:9], mixed[..., 9:], weights, depth_map

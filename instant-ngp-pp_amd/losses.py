@@ -9,20 +9,17 @@ from . import vren
 
 
 def compute_scale_and_shift(prediction, target):
-    """least-squares scale/shift aligning prediction to target (losses.py:7-30)"""
-    a_00 = torch.sum(prediction * prediction)
-    a_01 = torch.sum(prediction)
-    a_11 = torch.sum(torch.ones_like(prediction))
-    b_0 = torch.sum(prediction * target)
-    b_1 = torch.sum(target)
-    det = a_00 * a_11 - a_01 * a_01
-    if det != 0:
-        x_0 = (a_11 * b_0 - a_01 * b_1) / det
-        x_1 = (-a_01 * b_0 + a_00 * b_1) / det
-    else:
-        x_0 = torch.zeros((), device=prediction.device)
-        x_1 = torch.zeros((), device=prediction.device)
-    return x_0, x_1
+    """Least-squares (scale, shift) with scale*prediction + shift ~ target (losses.py:7-30): the 2x2
+    normal equations [[sum p^2, sum p], [sum p, n]] [s, t]^T = [sum p*target, sum target]^T solved by
+    Cramer's rule; a singular system gives (0, 0)."""
+    n = prediction.new_tensor(float(prediction.numel()))
+    s_pp, s_p = (prediction * prediction).sum(), prediction.sum()
+    s_pt, s_t = (prediction * target).sum(), target.sum()
+    det = s_pp * n - s_p * s_p
+    if det == 0:
+        zero = prediction.new_zeros(())
+        return zero, zero
+    return (n * s_pt - s_p * s_t) / det, (s_pp * s_t - s_p * s_pt) / det
 
 
 class DistortionLoss(torch.autograd.Function):
@@ -111,61 +108,74 @@ class ExponentialAnnealingWeight():
 
 
 class NeRFLoss(nn.Module):
+    """Per-ray loss terms of the reference (losses.py:71-140) under the same dictionary keys and
+    weights; the trainer reduces them with sum(term.mean()) (train.py:307).  Optional terms are
+    switched on by the same keyword flags: embed_msk, normal_ref, normal_mono, semantic, depth_mono."""
+
+    WEIGHTS = dict(lambda_opa=2e-4, lambda_distortion=3e-4, lambda_depth_mono=1, lambda_normal_mono=1e-3,
+                   lambda_normal_ref_rp=1e-3, lambda_normal_ref_ro=1e-3, lambda_sky=1e-1, lambda_semantic=4e-2)
+
     def __init__(self):
         super().__init__()
-        self.lambda_opa = 2e-4
-        self.lambda_distortion = 3e-4
-        self.lambda_depth_mono = 1
-        self.lambda_normal_mono = 1e-3
-        self.lambda_normal_ref_rp = 1e-3
-        self.lambda_normal_ref_ro = 1e-3
-        self.lambda_sky = 1e-1
-        self.lambda_semantic = 4e-2
+        for name, value in self.WEIGHTS.items():
+            setattr(self, name, value)
         self.Annealing = ExponentialAnnealingWeight(max=1, min=6e-2, k=1e-3)
         self.CrossEntropyLoss = nn.CrossEntropyLoss(ignore_index=256)
 
+    # ---- the individual terms -------------------------------------------------------------
+    @staticmethod
+    def _colour(results, target, mask=None):
+        err = torch.square(results['rgb'] - target['rgb'])
+        return err if mask is None else (1 - mask) * err
+
+    def _opacity_entropy(self, results):
+        o = results['opacity'] + 1e-10            # -o log o: pushes the opacity of a ray towards 0 or 1
+        return self.lambda_opa * (-o * torch.log(o))
+
+    def _distortion(self, results):
+        return self.lambda_distortion * DistortionLoss.apply(results['ws'], results['deltas'], results['ts'],
+                                                             results['rays_a'])
+
+    def _normal_mono(self, results, target):
+        n_pred = F.normalize(results['normal_pred'], dim=-1)
+        n_gt = F.normalize(target['normal'], dim=-1)
+        return self.lambda_normal_mono * ((n_pred - n_gt).abs() - 0.1 * n_pred * n_gt)
+
+    def _depth_mono(self, results, target, scene_scale):
+        depth_2d = target['depth'] / 25
+        valid = depth_2d > 0
+        scale, shift = compute_scale_and_shift(results['depth'][valid].detach(), depth_2d[valid])
+        falloff = torch.exp(-results['depth'].detach() / scene_scale)
+        return valid.to(depth_2d.dtype) * self.lambda_depth_mono * falloff * \
+            torch.square(scale * results['depth'] + shift - depth_2d)
+
+    # ---- dictionary of terms ---------------------------------------------------------------
     def forward(self, results, target, **kwargs):
         d = {}
         if kwargs.get('embed_msk', False):
             d['r_ms'], _ = self.mask_regularize(kwargs['mask'], self.Annealing.getWeight(kwargs['step']), 0)
-            d['rgb'] = (1 - kwargs['mask']) * (results['rgb'] - target['rgb']) ** 2
+            d['rgb'] = self._colour(results, target, kwargs['mask'])
         else:
-            d['rgb'] = (results['rgb'] - target['rgb']) ** 2
-
-        o = results['opacity'] + 1e-10
-        d['opacity'] = self.lambda_opa * (-o * torch.log(o))  # push opacity towards 0 or 1
-
+            d['rgb'] = self._colour(results, target)
+        d['opacity'] = self._opacity_entropy(results)
         if self.lambda_distortion > 0:
-            d['distortion'] = self.lambda_distortion * \
-                DistortionLoss.apply(results['ws'], results['deltas'], results['ts'], results['rays_a'])
-
+            d['distortion'] = self._distortion(results)
         if kwargs.get('normal_ref', False):
             d['normal_ref_rp'] = self.lambda_normal_ref_rp * results['Rp']
             d['normal_ref_ro'] = self.lambda_normal_ref_ro * results['Ro']
-
         if kwargs.get('normal_mono', False):
-            normal_pred = F.normalize(results['normal_pred'], dim=-1)
-            normal_gt = F.normalize(target['normal'], dim=-1)
-            d['normal_mono'] = self.lambda_normal_mono * \
-                (torch.abs(normal_pred - normal_gt) + 0.1 * (-(normal_pred * normal_gt)))
-
+            d['normal_mono'] = self._normal_mono(results, target)
         if kwargs.get('semantic', False):
             d['CELoss'] = self.lambda_semantic * self.CrossEntropyLoss(results['semantic'], target['label'])
-            sky_mask = torch.where(target['label'] == 4, 1., 0.)
-            d['sky_depth'] = self.lambda_sky * sky_mask * torch.exp(-results['depth'])
-
+            is_sky = (target['label'] == 4).to(results['depth'].dtype)
+            d['sky_depth'] = self.lambda_sky * is_sky * torch.exp(-results['depth'])
         if kwargs.get('depth_mono', False):
-            depth_2d = target['depth'] / 25
-            mask = depth_2d > 0
-            weight = torch.where(mask, 1., 0.)
-            scale, shift = compute_scale_and_shift(results['depth'][mask].detach(), depth_2d[mask])
-            d['depth_mono'] = weight * self.lambda_depth_mono * \
-                torch.exp(-results['depth'].detach() / kwargs.get('scale', 1)) * \
-                (scale * results['depth'] + shift - depth_2d) ** 2
+            d['depth_mono'] = self._depth_mono(results, target, kwargs.get('scale', 1))
         return d
 
     def mask_regularize(self, mask, size_delta, digit_delta):
-        focus_epsilon = 0.02
-        loss_focus_size = torch.mean(torch.pow(mask, 2)) * size_delta
-        loss_focus_digit = torch.mean(1 / ((mask - 0.5) ** 2 + focus_epsilon)) * digit_delta
-        return loss_focus_size, loss_focus_digit
+        """keeps the transient mask small (size term) and binary (digit term)"""
+        eps = 0.02
+        size_term = mask.pow(2).mean() * size_delta
+        digit_term = (1 / ((mask - 0.5).pow(2) + eps)).mean() * digit_delta
+        return size_term, digit_term

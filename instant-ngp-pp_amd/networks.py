@@ -625,29 +625,29 @@ class NGP(nn.Module):
 
     @torch.no_grad()
     def mark_invisible_cells(self, K, poses, img_wh, chunk=64 ** 3):
-        """cells no camera sees get density -1 (never updated); run once before training."""
-        N_cams = poses.shape[0]
+        """Cells that no camera sees, or that lie in front of a camera but closer than NEAR_DISTANCE,
+        get density -1 and are never updated again; `count_grid` keeps the fraction of cameras that
+        see each cell (networks.py:336-377).  Run once before training.
+        K (3,3) intrinsics, poses (N,3,4) camera-to-world, img_wh (w, h)."""
+        n_cams = poses.shape[0]
+        w, h = img_wh
+        rot_t = poses[:, :3, :3].transpose(1, 2)                       # world -> camera rotations
+        # one 3x4 projection per camera: pixel-homogeneous coordinates = proj @ [x_world; 1]
+        proj = K @ torch.cat([rot_t, -rot_t @ poses[:, :3, 3:]], 2)
         self.count_grid = torch.zeros_like(self.density_grid)
-        w2c_R = poses[:, :3, :3].transpose(1, 2)
-        w2c_T = -w2c_R @ poses[:, :3, 3:]
-        cells = self.get_all_cells()
-        for c in range(self.cascades):
-            indices, coords = cells[c]
-            for i in range(0, len(indices), chunk):
-                xyzs = coords[i:i + chunk] / (self.grid_size - 1) * 2 - 1
-                s = min(2 ** (c - 1), self.scale)
-                half_grid_size = s / self.grid_size
-                xyzs_w = (xyzs * (s - half_grid_size)).T
-                xyzs_c = w2c_R @ xyzs_w + w2c_T
-                uvd = K @ xyzs_c
-                uv = uvd[:, :2] / uvd[:, 2:]
-                in_image = (uvd[:, 2] >= 0) & (uv[:, 0] >= 0) & (uv[:, 0] < img_wh[0]) & \
-                           (uv[:, 1] >= 0) & (uv[:, 1] < img_wh[1])
-                covered_by_cam = (uvd[:, 2] >= NEAR_DISTANCE) & in_image
-                self.count_grid[c, indices[i:i + chunk]] = count = covered_by_cam.sum(0) / N_cams
-                too_near_to_any_cam = ((uvd[:, 2] < NEAR_DISTANCE) & in_image).any(0)
-                valid_mask = (count > 0) & (~too_near_to_any_cam)
-                self.density_grid[c, indices[i:i + chunk]] = torch.where(valid_mask, 0., -1.)
+        for c, (indices, coords) in enumerate(self.get_all_cells()):
+            s = min(2 ** (c - 1), self.scale)
+            centres = (coords.to(_f32) / (self.grid_size - 1) * 2 - 1) * (s - s / self.grid_size)
+            for lo in range(0, len(indices), chunk):
+                sel = indices[lo:lo + chunk]
+                uvd = torch.einsum('nij,mj->nim', proj[:, :, :3], centres[lo:lo + chunk]) + proj[:, :, 3:]
+                depth = uvd[:, 2]
+                u, v = uvd[:, 0] / depth, uvd[:, 1] / depth
+                inside = (depth >= 0) & (u >= 0) & (u < w) & (v >= 0) & (v < h)
+                seen = (inside & (depth >= NEAR_DISTANCE)).sum(0) / n_cams
+                too_close = (inside & (depth < NEAR_DISTANCE)).any(0)
+                self.count_grid[c, sel] = seen
+                self.density_grid[c, sel] = torch.where((seen > 0) & ~too_close, 0.0, -1.0)
 
     @torch.no_grad()
     def update_density_grid(self, density_threshold, warmup=False, decay=0.95, erode=False):

@@ -512,6 +512,31 @@ def g9_density_grid_update():
     cases["density_threshold"] = np.float64(thr)
     npz("g9_density_grid_update.npz", **cases)
 
+    # ---- G11: mark_invisible_cells (networks.py:336-377) on a few cameras, two of them inside the box so
+    # that the "too near to a camera" rule fires; scale 0.5 (one cascade) and scale 2 (three cascades)
+    vis = {}
+    for tag, scale in (("a", 0.5), ("b", 2.0)):
+        torch.manual_seed(SEED + 12)
+        m = ref_net.NGP(scale=scale)
+        G = m.grid_size
+        m.register_buffer("density_grid", torch.zeros(m.cascades, G ** 3))
+        m.register_buffer("grid_coords", torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32)] * 3,
+                                                                    indexing="ij"), -1).reshape(-1, 3))
+        n_cam = 7
+        pos = torch.nn.functional.normalize(torch.randn(n_cam, 3), dim=-1) * 1.5
+        pos[-2:] *= 0.15                                   # cameras inside the scene box
+        fwd = -torch.nn.functional.normalize(pos, dim=-1)
+        up = torch.tensor([0.0, 0.0, 1.0]).expand_as(fwd)
+        right = torch.nn.functional.normalize(torch.cross(fwd, up, dim=-1), dim=-1)
+        down = torch.cross(fwd, right, dim=-1)
+        poses = torch.stack([right, down, fwd, pos], -1)   # (n,3,4) c2w, [right down front]
+        K = torch.tensor([[300.0, 0, 100.0], [0, 300.0, 100.0], [0, 0, 1.0]])
+        m.mark_invisible_cells(K, poses, (200, 200))
+        vis[tag + "_scale"], vis[tag + "_poses"], vis[tag + "_K"] = np.float64(scale), poses, K
+        vis[tag + "_invisible_bits"] = np.packbits((m.density_grid.numpy() < 0).reshape(-1))
+        vis[tag + "_count_sub"] = m.count_grid.numpy()[:, ::101].copy()
+    npz("g11_invisible_cells.npz", **vis)
+
 
 if __name__ == "__main__":
     cf, rn = import_reference()

@@ -1297,6 +1297,29 @@ def test_normal_ref_step_matches_reference_golden(ngp, golden, monkeypatch):
         assert abs(np.sqrt((mine.astype(np.float64) ** 2).sum()) - l2) < 5e-3 * l2, k
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_mark_invisible_cells_matches_reference_golden(ngp, golden, tag):
+    """NGP.mark_invisible_cells against the G11 fixture (the reference's own method on the CPU):
+    cells outside every camera frustum, or in front of a camera but nearer than NEAR_DISTANCE, are -1;
+    count_grid = fraction of cameras that see the cell.  a: scale 0.5; b: scale 2 (three cascades)."""
+    g = golden("g11_invisible_cells.npz")
+    scale = float(g[tag + "_scale"])
+    model = ngp.networks.NGP(scale=scale).to(DEV)
+    G = model.grid_size
+    model.register_buffer("density_grid", torch.zeros(model.cascades, G ** 3, device=DEV))
+    coords = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=DEV)] * 3, indexing="ij"), -1)
+    model.register_buffer("grid_coords", coords.reshape(-1, 3).contiguous())
+    model.mark_invisible_cells(T(g[tag + "_K"]), T(g[tag + "_poses"]), (200, 200))
+    mine = (N(model.density_grid) < 0).reshape(-1)
+    ref = np.unpackbits(g[tag + "_invisible_bits"]).astype(bool)
+    assert set(np.unique(N(model.density_grid))) <= {0.0, -1.0}
+    # a cell centre that projects within fp32 rounding of an image border may fall on either side
+    assert (mine != ref).mean() < 1e-4, (mine != ref).mean()
+    assert ref.any() and not ref.all()
+    cnt = N(model.count_grid)[:, ::101]
+    assert (np.abs(cnt - g[tag + "_count_sub"]) > 1e-6).mean() < 1e-3
+
+
 def test_differentiable_normals_h4(ngp):
     """--normal_ref path: a loss on normals_raw reaches the density table through the grid's double
     backward; checked against a central difference along a random direction in parameter space."""

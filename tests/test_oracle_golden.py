@@ -158,3 +158,28 @@ def test_g6_field_wiring_matches_reference_ngp(golden, tag):
     # forward_test returns the same quantities with the two normal maps swapped (networks.py:282)
     close(g[f"{tag}_test_normals_pred"], g[f"{tag}_fwd_normals_pred"], rtol=0, atol=0)
     close(g[f"{tag}_test_normals_raw"], g[f"{tag}_fwd_normals_raw"], rtol=1e-5, atol=1e-6)
+
+
+def test_g1_g2_torch_surface_functions(golden):
+    """custom_functions.raw2outputs / sample_pdf of the package (pure torch, the reference's names and
+    signatures) against the reference's own outputs"""
+    import sys
+    import os
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import ngp_amd  # noqa: F401
+    from ngp_amd import custom_functions as cf
+    g = golden("g1_raw2outputs.npz")
+    for i in range(int(g["n_cases"])):
+        p = f"c{i}_"
+        if g[p + "z"].shape[1] == 1:
+            continue  # the reference degenerates for one sample (empty dists)
+        outs = cf.raw2outputs(torch.from_numpy(g[p + "raw"]), torch.from_numpy(g[p + "z"]), torch.from_numpy(g[p + "d"]),
+                              classes=int(g[p + "classes"]))
+        for name, o in zip(("opacity", "rgb", "normal_raw", "normal_pred", "sem", "ws", "depth"), outs):
+            close(o.numpy(), g[p + name], rtol=2e-5, atol=2e-6)
+    g = golden("g2_sample_pdf.npz")
+    for i in range(int(g["n_cases"])):
+        p = f"c{i}_"
+        out = cf.sample_pdf(torch.from_numpy(g[p + "bins"]), torch.from_numpy(g[p + "w"]), int(g[p + "n"]), det=True)
+        assert (np.abs(out.numpy() - g[p + "out"]) > 5e-4).mean() < 0.005
