@@ -16,7 +16,9 @@ PYTHON wiring of the field and of the renderer; the primitives themselves are pi
 (known-answer tests of the oracle, bit / tolerance parity of the HIP kernels against it).
 
 Fixtures hold numbers only (inputs and the reference's outputs).  Seed 20220806 = the
-reference's own seed (train.py:402).
+reference's own seed (train.py:402).  G1-G7, G9, G11 regenerate byte-identically; G8 / G10 contain
+gradients accumulated by multi-threaded CPU index_add and differ in the last bits from run to run
+(the committed files are the ones the tests were run against).  A full run takes about 5 minutes.
 """
 import os
 import sys
