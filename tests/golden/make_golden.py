@@ -264,6 +264,16 @@ def g6_ngp_field():
             cases[f"{tag}_test_{k}"] = v.detach()
         with torch.no_grad():
             cases[f"{tag}_density"] = model.density(torch.from_numpy(x.copy()))
+    # skybox branch (networks.py:128-148, 284-291): SH degree 3 of the normalised direction -> 32 -> 3, sigmoid
+    torch.manual_seed(SEED + 6)
+    model = ref_net.NGP(scale=0.5, use_skybox=True)
+    with torch.no_grad():
+        p = model.skybox_rgb_net.params
+        p.copy_(torch.from_numpy((g.standard_normal(p.shape) * 0.3).astype(np.float32)))
+        cases["sky_params"] = p.detach().clone()
+        dsky = g.standard_normal((100, 3)).astype(np.float32)
+        cases["sky_d"] = dsky
+        cases["sky_rgb"] = model.forward_skybox(torch.from_numpy(dsky))
     npz("g6_ngp_field.npz", **cases)
 
 

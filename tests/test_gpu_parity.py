@@ -721,6 +721,16 @@ def test_field_matches_reference_ngp_golden(ngp, golden, tag):
     assert np.percentile((N(n_raw_t) * g[f"{tag}_test_normals_raw"]).sum(-1), 2) > 0.9995
 
 
+def test_skybox_matches_reference_ngp_golden(ngp, golden):
+    """forward_skybox (M4) against the reference's own NGP(use_skybox=True).forward_skybox (G6)"""
+    g = golden("g6_ngp_field.npz")
+    model = ngp.networks.NGP(scale=0.5, use_skybox=True).to(DEV)
+    with torch.no_grad():
+        model.skybox_rgb_net.params.copy_(T(g["sky_params"]))
+        out = model.forward_skybox(T(g["sky_d"]))
+    close(N(out), g["sky_rgb"], 2e-4, 1e-5)
+
+
 @pytest.mark.parametrize("scale", [8.0, 16.0])
 def test_field_forward_matches_oracle_unbounded(ngp, scale):
     """BASELINE configs 2/3 (Playground-like scale 8 with appearance codes, bicycle-like scale 16):
