@@ -2,7 +2,8 @@
 TEST INFRASTRUCTURE ONLY (parity checks of the GPU field and the timed cpu_baseline leg).
 
 The hash grid / SH / MLP semantics are tiny-cuda-nn's (parity with the real
-tcnn is unpinned, see ngp_oracle.c).  Weights are taken from a state dict with the reference's
+tcnn is unpinned, see ngp_oracle.c).  The WIRING of the field is pinned: tests/test_oracle_golden.py
+checks this class against the outputs of the reference's own models/networks.py::NGP (fixture G6).  Weights are taken from a state dict with the reference's
 key names (`xyz_encoder.params`, `xyz_net.0.weight`, ..., `rgb_net.params`).
 """
 import numpy as np

@@ -13,7 +13,13 @@
  * reference has no tests, so the ray marcher, distortion/ref losses and the
  * tiny-cuda-nn parts (hash grid, SH) are restated from the sources/semantics cited
  * at each function and pinned only by known-answer tests: PARITY UNPINNED for
- * those rows.
+ * those rows at the level of the individual primitive.  What IS
+ * pinned by the reference's own code beyond the compositing maths: these entry
+ * points serve as the `vren` module under the reference's own models/rendering.py,
+ * losses.py and networks.py when make_golden.py runs them on the CPU (fixtures
+ * G7-G11: render() train and test paths, a whole training step, the --normal_ref
+ * step, update_density_grid, mark_invisible_cells), so their calling conventions,
+ * in-place semantics and the Python logic around them are the reference's.
  *
  * All arithmetic is fp32 with the reference's expression order; compile with
  * -ffp-contract=off so that no FMA contraction changes results.
