@@ -243,8 +243,15 @@ def main():
         # 512 B/sample dL_dy stream, which it reports as 268 B).
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))[dom]
+            pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pmc = pmc_all[dom]
             traffic = (2 * pmc["fetch_bytes_per_sample"] + pmc["write_bytes_per_sample"]) * kern[dom]["avg_samples"]
+            # achieved HBM rate of every hash-grid kernel from the same PMC passes (FETCH_SIZE as reported, i.e.
+            # a lower bound for the gathers, + WRITE_SIZE) over the launch time measured in this run
+            for name in grid_names:
+                b = (pmc_all[name]["fetch_bytes_per_sample"] + pmc_all[name]["write_bytes_per_sample"]) * kern[name]["avg_samples"]
+                kern[name]["hbm_bytes_pmc"] = b
+                kern[name]["hbm_GBps_pmc"] = b / (kern[name]["avg_ms"] * 1e-3) / 1e9
         except Exception:
             pass
         roofline = {
