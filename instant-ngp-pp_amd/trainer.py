@@ -254,9 +254,9 @@ class NGPTrainer:
         # lr of the epoch this step belongs to (the scheduler ticks at epoch boundaries)
         lr = self.lr_at(min((self.global_step - 1) // self.steps_per_epoch, self.num_epochs))
         if not self.sharded:
-            # clip + Adam stream 6.4 GB and touch no ray data: run them on a side stream so the next
-            # step's ray generation / AABB / marcher (latency bound, 128 waves) overlap; the field
-            # waits on `_params_ready` before it reads a parameter.
+            # clip + Adam stream 6.4 GB and touch no ray data: they run on the optimizer stream, the
+            # field waits on `_params_ready` / `_rgb_params_ready` where it first reads the respective
+            # parameters (the ray-only front of the next step is on MarchAhead's stream anyway).
             n = self.flat_grad.numel()
             main = torch.cuda.current_stream()
             side = self._opt_stream
