@@ -1330,6 +1330,23 @@ def test_mark_invisible_cells_matches_reference_golden(ngp, golden, tag):
     assert (np.abs(cnt - g[tag + "_count_sub"]) > 1e-6).mean() < 1e-3
 
 
+def test_two_rank_sharded_training_matches_single_rank():
+    """N > 1 path on the GPU box: two ranks on this one GPU over gloo (RCCL needs a GPU per rank; the
+    collective pattern and the sharded optimizer are the same code) train 5 steps with reduce-scatter
+    / sharded clip + Adam / all-gather; both ranks must end bit-identical, and equal — up to summation
+    order — to one process training on the union of the two ray batches (tests/dp_worker.py)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, NGP_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "tests", "dp_worker.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "DP_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
 def test_differentiable_normals_h4(ngp):
     """--normal_ref path: a loss on normals_raw reaches the density table through the grid's double
     backward; checked against a central difference along a random direction in parameter space."""
