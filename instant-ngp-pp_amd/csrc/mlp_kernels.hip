@@ -77,7 +77,9 @@ __device__ __forceinline__ float act_grad_from_output(float y, int act)
 // staging path of a GEMM (softplus' = 1 - exp(-y), v_exp_f32)
 __device__ __forceinline__ float act_grad_fast(float y, int act)
 {
-    return act == NGP_ACT_SOFTPLUS ? 1.0f - __expf(-y) : (act == NGP_ACT_RELU ? (y > 0.0f ? 1.0f : 0.0f) : act_grad_from_output(y, act));
+    if (act == NGP_ACT_SOFTPLUS)   // 1 - exp(-y) cancels for tiny y: two Taylor terms there (relative error < 2e-7)
+        return y < 1e-3f ? y * (1.0f - 0.5f * y) : 1.0f - __expf(-y);
+    return act == NGP_ACT_RELU ? (y > 0.0f ? 1.0f : 0.0f) : act_grad_from_output(y, act);
 }
 
 constexpr int BK = 32;
