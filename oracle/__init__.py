@@ -29,7 +29,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        # NGP_ORACLE_SO: a sanitizer build of ngp_oracle.c (oracle/Makefile `asan`), CPU tests only
+        _lib = C.CDLL(os.environ.get("NGP_ORACLE_SO") or build())
         _lib.ngp_cpu_grid_layout.restype = C.c_int64
     return _lib
 
