@@ -14,5 +14,7 @@ _REAL = "instant-ngp-pp_amd"
 _pkg = importlib.import_module(_REAL)
 sys.modules[__name__] = _pkg
 for _sub in ("_lib", "build", "vren", "tinycudann", "torch_scatter", "custom_functions", "rendering", "networks",
-             "losses", "metrics", "synthetic", "trainer", "ckpt", "datasets"):
+             "losses", "metrics", "synthetic", "trainer", "ckpt", "datasets", "datasets.base", "datasets.ray_utils",
+             "datasets.color_utils", "datasets.colmap_utils", "datasets.nerf", "datasets.colmap", "datasets.tnt",
+             "datasets.nsvf", "datasets.nerfpp", "datasets.export"):
     sys.modules[f"{__name__}.{_sub}"] = importlib.import_module(f"{_REAL}.{_sub}")

@@ -1002,6 +1002,40 @@ def test_train_from_dataset_directory(ngp, tmp_path):
     assert len(psnrs) == 2 and min(psnrs) > 22.0, psnrs
 
 
+@pytest.mark.parametrize("fmt", ["colmap", "tnt"])
+def test_train_from_other_dataset_formats(ngp, tmp_path, fmt):
+    """SURVEY §8(f) rank 4 loaders feeding the hot path: the analytic proxy exported as a COLMAP model
+    (binary sparse/0 + images, every 8th frame held out) or as a Tanks-and-Temples directory
+    (pose/*.txt, intrinsics.txt, 0_/1_ prefixes), loaded onto the GPU, trained and evaluated.  Both
+    loaders rescale the cameras (by the largest camera distance), so the scene is learnt at a
+    different size than in the Blender-format test — the pipeline must not care."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train_dataset as td
+    from ngp_amd.datasets import dataset_dict, export
+    from ngp_amd.synthetic import LegoProxy
+    scene = LegoProxy(n_images=26, img_wh=(64, 64), device=DEV)
+    images = export.render_scene_views(scene, range(26), rgba=False, n_quad=128)
+    c2w = scene.poses.cpu().numpy().astype(np.float64)
+    K = scene.K.cpu().numpy().astype(np.float64)
+    root = str(tmp_path / "scene")
+    if fmt == "colmap":
+        export.export_colmap(root, images, c2w, K, shuffle_seed=3)
+        n_train, n_test = 22, 4
+    else:
+        export.export_tnt(root, images, c2w, K, [1 if i % 8 == 0 else 0 for i in range(26)])
+        n_train, n_test = 22, 4
+    train_set = dataset_dict[fmt](root, "train", 1.0, device=DEV)
+    test_set = dataset_dict[fmt](root, "test", 1.0, device=DEV)
+    assert train_set.rays.is_cuda and train_set.rays.shape == (n_train, 64 * 64, 3) and len(test_set) == n_test
+    assert float(train_set.poses[:, :, 3].norm(dim=-1).max()) <= 1.0 + 1e-5      # cameras were rescaled
+    torch.manual_seed(43)
+    model = td.build_model(0.5, DEV)
+    tr = td.train(model, train_set, num_epochs=2, steps_per_epoch=200, batch_size=2048, lr=1e-2)
+    assert tr.global_step == 400
+    psnrs = td.evaluate(model, test_set)
+    assert len(psnrs) == n_test and min(psnrs) > 21.0, psnrs
+
+
 def test_trainer_fused_loss_path_matches_module_path(ngp):
     """NGPTrainer with the fused loss kernels (directly seeded backward) follows the same
     trajectory as with the reference's NeRFLoss module + loss.backward()."""

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Trains on a NeRF-Synthetic scene directory with the reference's recipe and evaluates the test
-split (what `python train.py --root_dir ... --dataset_name nsvf/nerf` + validation do in the
+"""Trains on a scene directory with the reference's recipe and evaluates the test split (what
+`python train.py --root_dir ... --dataset_name nerf|nsvf|colmap|tnt|nerfpp` + validation do in the
 reference: train.py:82-392).  GPU only.
 
   python tools/train_dataset.py --root_dir /data/nerf_synthetic/lego --num_epochs 20
+  python tools/train_dataset.py --root_dir /data/tnt/Playground --dataset_name tnt --scale 8 --exp_step_factor 0.00390625
   python tools/train_dataset.py --make_proxy /tmp/proxy --downsample 0.25 --num_epochs 2   # no dataset at hand
 """
 import argparse
@@ -17,7 +18,7 @@ sys.path.insert(0, ROOT)
 import torch
 import ngp_amd  # noqa: F401
 from ngp_amd import ckpt
-from ngp_amd.datasets import NeRFDataset, get_rays, write_synthetic_dataset
+from ngp_amd.datasets import dataset_dict, get_rays, write_synthetic_dataset
 from ngp_amd.metrics import psnr
 from ngp_amd.networks import NGP
 from ngp_amd.rendering import render
@@ -33,10 +34,12 @@ def build_model(scale, device):
     return model
 
 
-def train(model, train_set, num_epochs, steps_per_epoch, batch_size, lr, log_every=0):
+def train(model, train_set, num_epochs, steps_per_epoch, batch_size, lr, log_every=0, exp_step_factor=0.0,
+          render_kwargs=None):
     """the reference's schedule (NGPTrainer) fed by the dataset's own sampler, one batch ahead"""
     train_set.batch_size = batch_size
-    trainer = NGPTrainer(model, lr=lr, num_epochs=num_epochs, steps_per_epoch=steps_per_epoch)
+    trainer = NGPTrainer(model, lr=lr, num_epochs=num_epochs, steps_per_epoch=steps_per_epoch,
+                         exp_step_factor=exp_step_factor, render_kwargs=render_kwargs)
 
     def next_batch():
         s = train_set[0]
@@ -59,7 +62,7 @@ def train(model, train_set, num_epochs, steps_per_epoch, batch_size, lr, log_eve
 
 
 @torch.no_grad()
-def evaluate(model, test_set, chunk=131072, save_dir=None):
+def evaluate(model, test_set, chunk=131072, save_dir=None, exp_step_factor=0.0):
     """per-image PSNR of the test split through render(test_time=True) (train.py:347-392)"""
     w, h = test_set.img_wh
     out = []
@@ -67,7 +70,8 @@ def evaluate(model, test_set, chunk=131072, save_dir=None):
         s = test_set[i]
         o, d = get_rays(test_set.directions, s["pose"])
         o, d = o.contiguous(), d.contiguous()
-        rgb = torch.cat([render(model, o[j:j + chunk], d[j:j + chunk], test_time=True, T_threshold=1e-2)["rgb"]
+        rgb = torch.cat([render(model, o[j:j + chunk], d[j:j + chunk], test_time=True, T_threshold=1e-2,
+                                exp_step_factor=exp_step_factor)["rgb"]
                          for j in range(0, o.shape[0], chunk)], 0).clamp(0, 1)
         out.append(float(psnr(rgb, s["rgb"])))
         if save_dir:
@@ -81,9 +85,12 @@ def evaluate(model, test_set, chunk=131072, save_dir=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--root_dir")
+    ap.add_argument("--dataset_name", default="nerf", choices=sorted(dataset_dict))
     ap.add_argument("--make_proxy", help="write the analytic lego-proxy scene to this directory first and train on it")
     ap.add_argument("--downsample", type=float, default=1.0)
     ap.add_argument("--scale", type=float, default=0.5)
+    ap.add_argument("--exp_step_factor", type=float, default=0.0, help="1/256 for unbounded scenes (opt.py)")
+    ap.add_argument("--random_bg", action="store_true")
     ap.add_argument("--batch_size", type=int, default=8192)
     ap.add_argument("--num_epochs", type=int, default=20)
     ap.add_argument("--steps_per_epoch", type=int, default=1000)
@@ -99,14 +106,16 @@ def main():
         wh = int(800 * args.downsample)
         scene = LegoProxy(n_images=108, img_wh=(wh, wh), device=dev)
         root = write_synthetic_dataset(args.make_proxy, scene, n_train=100, n_test=8, rgba=False)
-    train_set = NeRFDataset(root, "train", args.downsample, device=dev)
-    test_set = NeRFDataset(root, "test", args.downsample, device=dev)
+    loader = dataset_dict[args.dataset_name]
+    train_set = loader(root, "train", args.downsample, device=dev)
+    test_set = loader(root, "test", args.downsample, device=dev)
     model = build_model(args.scale, dev)
     t0 = time.perf_counter()
-    train(model, train_set, args.num_epochs, args.steps_per_epoch, args.batch_size, args.lr, log_every=500)
+    train(model, train_set, args.num_epochs, args.steps_per_epoch, args.batch_size, args.lr, log_every=500,
+          exp_step_factor=args.exp_step_factor, render_kwargs={"random_bg": True} if args.random_bg else None)
     torch.cuda.synchronize()
     t_train = time.perf_counter() - t0
-    psnrs = evaluate(model, test_set, save_dir=args.save_dir)
+    psnrs = evaluate(model, test_set, save_dir=args.save_dir, exp_step_factor=args.exp_step_factor)
     if args.ckpt_path:
         ckpt.save_ckpt(model, args.ckpt_path)
     print(json.dumps({"train_s": t_train, "test_psnr_mean": sum(psnrs) / len(psnrs), "test_psnr": psnrs,
