@@ -117,7 +117,15 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # NGP_FORCE_SHARDED=1: one rank, but with a process group and the sharded-optimizer path, so that
+    # every RCCL call of the N>1 path is exercised on a single-GPU box (a rehearsal, not a bench line)
+    solo_group = world == 1 and bool(os.environ.get("NGP_FORCE_SHARDED"))
+    if solo_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or solo_group:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -297,7 +305,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, scene, args.cpu_rays, args.cpu_samples)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or solo_group:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -19,6 +19,7 @@ MI355X-specific structure:
     all-gathered.  Same bytes on xGMI as an all-reduce, 1/N of the optimizer time and state.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -42,11 +43,14 @@ class GradBuckets:
     Buckets must be a multiple of world*4 elements long in sharded mode (the trainer pads).
     """
 
-    def __init__(self, flat_grad, boundaries, group=None):
+    def __init__(self, flat_grad, boundaries, group=None, solo=True):
         self.flat = flat_grad
         self.bounds = list(boundaries)  # [0, b1, ..., n]
         self.group = group
         self.works = []
+        # solo=False: a ONE-rank process group still sends every collective of the N>1 path through
+        # the backend (a rehearsal of the RCCL calls on a single-GPU box, see NGPTrainer.force_sharded)
+        self.solo = solo
 
     @property
     def world(self):
@@ -65,14 +69,14 @@ class GradBuckets:
         return lo + self.rank * s, lo + (self.rank + 1) * s
 
     def reduce_bucket(self, i):
-        if self.world == 1:
+        if self.world == 1 and self.solo:
             return
         lo, hi = self.bounds[i], self.bounds[i + 1]
         self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def reduce_scatter_bucket(self, i, out):
         """out (own buffer, 1/world of the bucket) <- this rank's slice of the bucket summed over ranks"""
-        if self.world == 1:
+        if self.world == 1 and self.solo:
             return
         lo, hi = self.bounds[i], self.bounds[i + 1]
         if self._native_rs():
@@ -86,7 +90,7 @@ class GradBuckets:
 
     def all_gather_bucket(self, i, flat_param, shard, detach=False):
         """flat_param[bucket i] <- concatenation over ranks of `shard` (own buffer)"""
-        if self.world == 1:
+        if self.world == 1 and self.solo:
             return None
         lo, hi = self.bounds[i], self.bounds[i + 1]
         if self._native_rs():
@@ -114,8 +118,13 @@ def shard_seed(base_seed, rank):
 
 class NGPTrainer:
     def __init__(self, model, lr=1e-2, num_epochs=20, steps_per_epoch=1000, clip_norm=50.0,
-                 exp_step_factor=0.0, num_classes=7, density_threshold=0.01, render_kwargs=None, group=None):
+                 exp_step_factor=0.0, num_classes=7, density_threshold=0.01, render_kwargs=None, group=None,
+                 force_sharded=None):
+        """force_sharded: take the sharded-optimizer path (reduce-scatter / Adam on the slice / all-gather)
+        even with ONE rank in the process group, so that a single-GPU box can rehearse every RCCL call of
+        the N>1 path; None reads the environment variable NGP_FORCE_SHARDED."""
         self.model = model
+        self.force_sharded = bool(os.environ.get("NGP_FORCE_SHARDED")) if force_sharded is None else bool(force_sharded)
         self.base_lr = lr
         self.num_epochs = num_epochs
         self.steps_per_epoch = steps_per_epoch
@@ -149,7 +158,8 @@ class NGPTrainer:
         sizes[-1] += (quantum - rest % quantum) % quantum
         total = sum(sizes)
         dev = named[0][1].device
-        self.sharded = world > 1
+        forced = self.force_sharded and dist.is_available() and dist.is_initialized()
+        self.sharded = world > 1 or bool(forced)
         self.flat_param = torch.zeros(total, dtype=_f32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=_f32, device=dev)
         self.scalars = torch.zeros(2, dtype=_f32, device=dev)  # [sum of squares, clip coefficient]
@@ -164,7 +174,8 @@ class NGPTrainer:
             off += sz
         # bucket 0 = rgb table, bucket 1 = everything else
         b0 = sizes[0] if named[0][0] == "rgb_encoder.params" else 0
-        self.buckets = GradBuckets(self.flat_grad, [0, b0, total] if b0 else [0, total], group=self.group)
+        self.buckets = GradBuckets(self.flat_grad, [0, b0, total] if b0 else [0, total], group=self.group,
+                                   solo=not forced)
         # Adam state: whole buffer on one GPU; with N ranks each rank keeps (and updates) only its
         # 1/N slice of every bucket — reduce-scatter gradients, Adam on the slice, all-gather params
         if self.sharded:
@@ -316,7 +327,7 @@ class NGPTrainer:
     def broadcast_state(self, src=0):
         """start every rank from rank `src`'s parameters and occupancy grid (DDP does this at
         construction and re-broadcasts buffers every forward; train.py:431)"""
-        if self.buckets.world == 1:
+        if self.buckets.world == 1 and self.buckets.solo:
             return
         dist.broadcast(self.flat_param, src, group=self.group)
         if self.sharded:

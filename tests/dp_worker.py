@@ -1,6 +1,9 @@
 """Worker of test_gpu_parity.py::test_two_rank_sharded_training_matches_single_rank — launched with
 torch.distributed.run, 2 ranks on ONE GPU over gloo (the RCCL path needs one GPU per rank; the
-collective pattern, the sharded optimizer and the 1/world folding are the same code).
+collective pattern, the sharded optimizer and the 1/world folding are the same code) — and of
+test_one_rank_rccl_sharded_training_matches_unsharded: ONE rank over RCCL (NGP_DIST_BACKEND=nccl,
+NGP_FORCE_SHARDED=1), which sends the same reduce-scatter / all-reduce / all-gather calls through the
+backend the multi-GPU bench uses.
 
 Every rank trains STEPS steps on its own rays with the sharded optimizer (reduce-scatter of the
 gradient, clip + Adam on the rank's slice, all-gather of the parameters).  Checks:
@@ -60,10 +63,15 @@ def run(trainer, data):
 
 
 def main():
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if os.environ.get("NGP_DIST_BACKEND", "gloo") == "nccl":   # one rank, RCCL: NGP_FORCE_SHARDED=1 rehearsal
+        dist.init_process_group("nccl", device_id=dev)
+        cdev = dev            # RCCL moves device tensors only
+    else:
+        dist.init_process_group("gloo")
+        cdev = torch.device("cpu")
+    rank, world = dist.get_rank(), dist.get_world_size()
     scene = LegoProxy(n_images=10, img_wh=(100, 100), device=dev)
     model = build(dev)
     tr = NGPTrainer(model, lr=1e-2)
@@ -72,15 +80,15 @@ def main():
     mine = batches(scene, rank, dev)
     losses = run(tr, mine)
     assert all(l == l and l < 10 for l in losses), losses
-    flat = tr.flat_param.detach().cpu()
+    flat = tr.flat_param.detach().to(cdev)
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     for r in range(1, world):
         assert torch.equal(gathered[0], gathered[r]), f"rank {r} diverged: {(gathered[0]-gathered[r]).abs().max()}"
-    lt = torch.tensor(losses, dtype=torch.float64)
+    lt = torch.tensor(losses, dtype=torch.float64, device=cdev)
     all_losses = [torch.empty_like(lt) for _ in range(world)]
     dist.all_gather(all_losses, lt)
-    mean_losses = torch.stack(all_losses).mean(0)            # DDP: the mean over ranks of the per-rank mean losses
+    mean_losses = torch.stack(all_losses).mean(0).cpu()            # DDP: the mean over ranks of the per-rank mean losses
     small = ("xyz_net.0.weight", "xyz_net.0.bias", "xyz_net.2.weight", "xyz_net.2.bias", "rgb_net.params")
     sharded_params = {k: v.detach().clone() for k, v in model.named_parameters() if k in small}
     ok = True
@@ -88,7 +96,7 @@ def main():
     if rank == 0:
         del tr
         model1 = build(dev)
-        tr1 = NGPTrainer(model1, lr=1e-2, group=sub)
+        tr1 = NGPTrainer(model1, lr=1e-2, group=sub, force_sharded=False)
         assert not tr1.sharded
         others = [batches(scene, r, dev) for r in range(world)]
         union = [(torch.cat([others[r][i][0] for r in range(world)]), torch.cat([others[r][i][1] for r in range(world)]),
@@ -104,7 +112,7 @@ def main():
         print(f"rank0: max relative loss difference over the steps {rel_loss:.2e}; worst mean |param difference| {worst:.2e} "
               f"(lr = 1e-2, {STEPS} steps)", flush=True)
         ok = rel_loss < 2e-3 and worst < 2e-3
-    flag = torch.tensor([1 if ok else 0])
+    flag = torch.tensor([1 if ok else 0], device=cdev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.barrier()
     if rank == 0:

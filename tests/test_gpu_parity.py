@@ -1381,6 +1381,23 @@ def test_two_rank_sharded_training_matches_single_rank():
     assert out.returncode == 0 and "DP_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 
+def test_one_rank_rccl_sharded_training_matches_unsharded():
+    """The RCCL calls of the N > 1 path on a single-GPU box: one rank, backend nccl (= RCCL), sharded
+    optimizer forced on (NGP_FORCE_SHARDED=1) — reduce_scatter_tensor from the encoder hook, the norm
+    all-reduce, Adam on the slice, the two detached all_gather_into_tensor works the next forward
+    waits on — must reproduce the unsharded run on the same rays (tests/dp_worker.py)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, NGP_DIST_BACKEND="nccl", NGP_FORCE_SHARDED="1", OMP_NUM_THREADS="4")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "tests", "dp_worker.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "DP_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
 def test_bench_line_contract():
     """bench.py prints ONE JSON line with the fields the driver and the judge read (a short run:
     20 set-up steps, 1 warm-up, 3 timed; the CPU baseline leg included with a small sample)."""
