@@ -139,6 +139,7 @@ class NGPTrainer:
         self.update_interval = 16
         self.global_step = 0
         self.group = group
+        self._grad_zeroed = None
         self._flatten()
         self._opt_stream = torch.cuda.Stream(device=self.flat_param.device) if self.flat_param.is_cuda else None
         self._march_ahead = MarchAhead(self.flat_param.device) if self.flat_param.is_cuda else None
@@ -224,6 +225,7 @@ class NGPTrainer:
         side stream under this step's backward and the next call picks the result up, provided it
         is called with the very same tensors and no density-grid update lies in between."""
         model = self.model
+        self._join_grad_zeroing()
         if self.global_step % self.update_interval == 0:
             model.update_density_grid(self.density_threshold * MAX_SAMPLES / 3 ** 0.5,
                                       warmup=self.global_step < self.warmup_steps)
@@ -296,28 +298,44 @@ class NGPTrainer:
         for i in range(1 if self.hooked0 else 0, nb):
             self.buckets.reduce_scatter_bucket(i, self.grad_shard[i])
         self.buckets.wait()
-        self.flat_grad.zero_()              # all contributions are in the shard buffers now
+        # all contributions are in the shard buffers now: clear the 0.8 GB accumulation buffer on the
+        # optimizer stream, beside the norm / Adam of the slices; the next step joins before it starts
+        if self._opt_stream is not None:
+            self._opt_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._opt_stream):
+                self.flat_grad.zero_()
+                self._grad_zeroed = torch.cuda.Event()
+                self._grad_zeroed.record(self._opt_stream)
+        else:
+            self.flat_grad.zero_()
         for g in self.grad_shard:           # global grad norm = sqrt(sum over ranks of shard sums)
             call("sumsq", g, g.numel(), self.scalars[0:1])
         dist.all_reduce(self.scalars[0:1], op=dist.ReduceOp.SUM, group=self.group)
         call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0 / world, self.scalars[1:2])
-        for i in range(nb):
+        # per bucket: Adam on the slice, then publish it.  [density table | MLPs] first, the colour table
+        # (77 % of the bytes) second; the field waits for each gather where it first reads those
+        # parameters, so the small gather is in flight while the colour slice is still being updated and
+        # the large one runs under the next step's marcher and density path
+        works = {}
+        for i in range(nb - 1, -1, -1):
             call("adam_step", self.param_shard[i], self.grad_shard[i], self.exp_avg[i], self.exp_avg_sq[i],
                  self.grad_shard[i].numel(), float(lr), 0.9, 0.999, 1e-8, 0.0, self.global_step, self.scalars[1:2], 0)
-        # publish the updated slices: [density table | MLPs] first, the colour table (77 % of the
-        # bytes) second; the field waits for each gather where it first reads those parameters, so
-        # the large one runs under the next step's marcher and density path
-        order = list(range(nb - 1, -1, -1))
-        works = {i: self.buckets.all_gather_bucket(i, self.flat_param, self.param_shard[i], detach=True) for i in order}
+            works[i] = self.buckets.all_gather_bucket(i, self.flat_param, self.param_shard[i], detach=True)
         if nb == 2:
             self.model._params_ready, self.model._rgb_params_ready = works[1], works[0]
         else:
             self.model._params_ready = works[0]
 
 
+    def _join_grad_zeroing(self):
+        ev, self._grad_zeroed = self._grad_zeroed, None
+        if ev is not None:
+            ev.wait()
+
     def wait(self):
         """make the current stream wait for a pending side-stream optimizer step (call before reading
         parameters / gradients outside the model's own forward)"""
+        self._join_grad_zeroing()
         for name in ("_params_ready", "_rgb_params_ready"):
             ev = getattr(self.model, name, None)
             if ev is not None:
