@@ -52,6 +52,7 @@ def parse():
                          "the steady-state regime the reference spends >98 %% of its 20k steps in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-march-ahead", action="store_true", help="march every batch inside its own step")
+    ap.add_argument("--step-times", action="store_true", help="print the host time of every timed step to stderr")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--cpu-samples", type=int, default=64)
     return ap.parse_args()
@@ -174,17 +175,29 @@ def main():
         # region's last step marches nothing.
         tot_samples = torch.zeros((), dtype=torch.int64, device=dev)
         last = None
+        stamps = [time.perf_counter()]
         for i in range(k):
             o, d, gt = batches[(i0 + i) % len(batches)]
             nxt = batches[(i0 + i + 1) % len(batches)][:2] if (i + 1 < k or feed_next_run) else None
             loss, res = trainer.step(o, d, gt, next_rays=None if args.no_march_ahead else nxt)
             tot_samples += res["total_samples"]
             last = (loss, res, gt)
+            stamps.append(time.perf_counter())
+        if args.step_times and not feed_next_run and rank == 0:
+            import gc
+            dt = [round((b - a) * 1e3, 2) for a, b in zip(stamps, stamps[1:])]
+            print("step host ms:", dt, "gc:", gc.get_count(), gc.get_stats()[-1], file=sys.stderr)
         return tot_samples, last
 
     for _ in range(args.pretrain):  # setup: fresh rays every step, not part of warm-up or timing
         o, d, gt = next_batch()
         trainer.step(o, d, gt)
+    # the interpreter's full collections walk every live object (modules, the 64 ray batches, ...): ~60 ms,
+    # once every few hundred steps, with the GPU draining meanwhile.  Objects alive now live for the whole
+    # run: move them out of the collector's sight (what a long-running training loop does as well).
+    import gc
+    gc.collect()
+    gc.freeze()
     run(args.warmup, 0, True)
     torch.cuda.synchronize()
     if world > 1:

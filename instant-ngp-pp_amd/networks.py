@@ -210,8 +210,8 @@ class _FieldFn(Function):
         E = 0 if embed_a is None else embed_a.shape[1]
         K = 144 + E
         Kp = model.rgb_net.padded_in
-        span = model.xyz_max - model.xyz_min
-        xn = ((x - model.xyz_min) / span).contiguous()
+        span = model._span()
+        xn = (x - model.xyz_min).div_(span)
 
         # density head
         feat = torch.empty(n, 128, dtype=_f32, device=dev)
@@ -292,7 +292,7 @@ class _FieldFn(Function):
         xe, re = model.xyz_encoder, model.rgb_encoder
         need = ctx.needs_input_grad  # (model, x, d, embed_a, xyz_table, W1, b1, W2, b2, rgb_table, rgb_p, nrm_p, sem_p)
         g_x = g_emb = g_xyz = g_W1 = g_b1 = g_W2 = g_b2 = g_rgbt = g_rgbp = g_nrm = g_sem = None
-        span = model.xyz_max - model.xyz_min
+        span = model._span()
         # A trainer that owns the gradient storage (NGPTrainer: one flat buffer, zeroed by its Adam
         # launch) registers the MLP gradients as sinks: the weight products accumulate straight into
         # them and autograd gets None — no zeros_like fill, no AccumulateGrad add per parameter.
@@ -518,6 +518,12 @@ class NGP(nn.Module):
         return sigmas, feat_rgb, grads / span
 
     # ------------------------------------------------------------------ full field
+    def _span(self):
+        sp = getattr(self, '_span_t', None)
+        if sp is None or sp.device != self.xyz_min.device:
+            sp = self._span_t = self.xyz_max - self.xyz_min
+        return sp
+
     def _inv_span(self):
         inv = getattr(self, '_inv_span_t', None)
         if inv is None or inv.device != self.xyz_min.device:

@@ -207,6 +207,21 @@ class NGPTrainer:
         self.hooked0 = bool(hasattr(self.model, "rgb_encoder") and self.sharded and b0)
         if self.hooked0:
             self.model.rgb_encoder.on_grad_ready = lambda: self.buckets.reduce_scatter_bucket(0, self.grad_shard[0])
+        elif (hasattr(self.model, "rgb_encoder") and b0 and dev.type == "cuda" and not self.sharded
+              and os.environ.get("NGP_NO_EARLY_NORM", "0") != "1"):
+            # one GPU: the colour table's share of the gradient norm (77 % of the entries) is summed
+            # right behind its scatter, beside the density head's backward, instead of on the path
+            # between the last scatter and Adam
+            self.model.rgb_encoder.on_grad_ready = self._early_norm_share
+        self._norm_share_armed = False   # step() arms it: exactly one backward per optimizer step
+        self._norm_share_fired = 0
+
+    def _early_norm_share(self):
+        if self._norm_share_armed:
+            self._norm_share_fired += 1
+            if self._norm_share_fired == 1:
+                b0 = self.buckets.bounds[1]
+                call("sumsq", self.flat_grad[0:b0], b0, self.scalars[0:1])
 
     # ------------------------------------------------------------------ schedule
     def lr_at(self, epoch):
@@ -242,6 +257,7 @@ class NGPTrainer:
             marched = ahead.take(rays_o, rays_d, self.exp_step_factor)
         results = render(model, rays_o, rays_d, exp_step_factor=self.exp_step_factor,
                          num_classes=self.num_classes, marched=marched, **self.render_kwargs)
+        self._norm_share_armed, self._norm_share_fired = True, 0   # one backward follows, then the optimizer step
         if self.fused_loss:
             # same value and gradients as sum(term.mean()) over NeRFLoss's default terms; the
             # gradients are seeded directly (no loss node, no multiplications by 1)
@@ -274,13 +290,19 @@ class NGPTrainer:
             main = torch.cuda.current_stream()
             side = self._opt_stream
             side.wait_stream(main)
+            b0 = self.buckets.bounds[1] if len(self.buckets.bounds) > 2 else 0
+            early = self._norm_share_armed and self._norm_share_fired == 1   # scalars[0] holds the colour table's share
+            self._norm_share_armed, self._norm_share_fired = False, 0
             with torch.cuda.stream(side):
-                self.scalars.zero_()
-                call("sumsq", self.flat_grad, n, self.scalars[0:1])
+                if early:
+                    call("sumsq", self.flat_grad[b0:n], n - b0, self.scalars[0:1])
+                else:
+                    self.scalars[0:1].zero_()
+                    call("sumsq", self.flat_grad, n, self.scalars[0:1])
                 call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2])
+                self.scalars[0:1].zero_()   # ready for the next step's early share
                 # two pieces: [density table | MLPs] first — the next forward starts on them — then
                 # the colour table, which the field does not read before its colour branch
-                b0 = self.buckets.bounds[1] if len(self.buckets.bounds) > 2 else 0
                 events = []
                 for lo, hi in ((b0, n), (0, b0)):
                     if hi > lo:

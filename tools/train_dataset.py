@@ -46,6 +46,9 @@ def train(model, train_set, num_epochs, steps_per_epoch, batch_size, lr, log_eve
         o, d = train_set.batch_rays(s)
         return o.contiguous(), d.contiguous(), s["rgb"].contiguous()
 
+    import gc
+    gc.collect()
+    gc.freeze()   # model, dataset and trainer live for the whole run: keep full collections cheap
     cur = next_batch()
     total = num_epochs * steps_per_epoch
     t0 = time.perf_counter()
