@@ -4,6 +4,7 @@
 #   r01_bench_kernel_stats.txt     rocprofv3 --kernel-trace --stats summary of the same command + timed-region table
 #   r01_bench_under_rocprof.json   the bench line printed while the profiler was attached
 #   r01_timeline.txt               one training step, kernel by kernel
+#   r01_timeline_grid_update_step.txt   a step that starts with a density-grid update
 #   r01_pmc_traffic.json           FETCH_SIZE / WRITE_SIZE of the grid kernels (separate --pmc passes)
 # Traces go to /tmp (they exceed the 64 MiB that travels back); only summaries are copied.
 set -e -o pipefail
@@ -19,6 +20,7 @@ python3 tools/prof_summary.py "$STATS" > gpurun_out/prof/r01_bench_kernel_stats.
 echo >> gpurun_out/prof/r01_bench_kernel_stats.txt
 python3 tools/timeline.py "$TRACE" region 40 >> gpurun_out/prof/r01_bench_kernel_stats.txt
 python3 tools/timeline.py "$TRACE" 3 > gpurun_out/prof/r01_timeline.txt
+python3 tools/timeline.py "$TRACE" update > gpurun_out/prof/r01_timeline_grid_update_step.txt
 if [ "$1" != "nopmc" ]; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 4 > gpurun_out/prof/pmc_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 4 > gpurun_out/prof/pmc_write.log 2>&1

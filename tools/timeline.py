@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Per-step timeline from a rocprofv3 `*_kernel_trace.csv`: picks one training step near the end of
-the run (steps are delimited by sumsq_kernel launches) and prints every kernel with its start offset,
+the run (steps are delimited by clip_coef_kernel launches, one per optimizer step) and prints every kernel with its start offset,
 duration, queue and the idle gap on the device before it.  Also prints the busy/idle split of the step.
 
 usage: timeline.py <kernel_trace.csv> [steps_from_end=3]
        timeline.py <kernel_trace.csv> region <K>     per-kernel time over the last K steps (bench.py's timed region)
+       timeline.py <kernel_trace.csv> update         the last step that contains a density-grid update (packbits)
 """
 import csv
 import re
@@ -23,19 +24,25 @@ def short(name):
     return s[:58]
 
 
-def main(path, back=3):
+STEP_MARK = "clip_coef_kernel"
+
+
+def main(path, back=3, with_update=False):
     rows = []
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
     rows.sort()
-    adam = [i for i, r in enumerate(rows) if "sumsq_kernel" in r[2]]
+    adam = [i for i, r in enumerate(rows) if STEP_MARK in r[2]]
     if len(adam) < back + 2:
         raise SystemExit("not enough steps in the trace")
-    lo, hi = adam[-back - 1], adam[-back]          # [adam of step k-1 ... adam of step k)
+    if with_update:
+        back = next(b for b in range(2, len(adam) - 1)
+                    if any("packbits" in r[2] for r in rows[adam[-b - 1]:adam[-b]]))
+    lo, hi = adam[-back - 1], adam[-back]          # [optimizer of step k-1 ... optimizer of step k)
     step = rows[lo:hi]
     t0 = step[0][0]
     wall = rows[hi][0] - t0
-    print(f"# step of {len(step)} launches, wall (sumsq start -> next sumsq start) {wall/1e3:.1f} us")
+    print(f"# step of {len(step)} launches, wall (clip_coef start -> next clip_coef start) {wall/1e3:.1f} us")
     print(f"{'start_us':>9s} {'dur_us':>8s} {'gap_us':>7s} {'q':>3s}  kernel")
     busy_end = t0
     idle = 0
@@ -52,8 +59,8 @@ def region(path, k):
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if "sumsq_kernel" in r[2]]
-    # the timed region ends with the optimizer of its last step: take the K steps before the last sumsq
+    marks = [i for i, r in enumerate(rows) if STEP_MARK in r[2]]
+    # the timed region ends with the optimizer of its last step: take the K steps before the last mark
     lo, hi = marks[-k - 1], marks[-1]
     sel = rows[lo:hi]
     wall = rows[hi][0] - rows[lo][0]
@@ -72,5 +79,7 @@ def region(path, k):
 if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[2] == "region":
         region(sys.argv[1], int(sys.argv[3]))
+    elif len(sys.argv) > 2 and sys.argv[2] == "update":
+        main(sys.argv[1], with_update=True)
     else:
         main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3)
