@@ -526,6 +526,194 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) g
     gemm_body<MODE, WM, WN, TM, TN, XF>(p);
 }
 
+// ---------------------------------------------------------------- streaming 2-layer forward (H = 128)
+// The weight matrix of a 128-wide layer is 64-80 KB: it fits the LDS of a CU next to nothing else,
+// and then nothing but the sample rows has to move.  One 512-thread workgroup per CU keeps W1 as
+// [n][k] (k contiguous, row stride K+4 floats: the 8 lanes of a ds_read_b128 phase hit 32 distinct
+// banks), W2 and b1 in LDS for its whole life; each of its 8 waves streams 32-row tiles on its own:
+//   A operand  : lane (row li, half lh) loads float4 x[row][8q+4lh .. +3] straight from global memory
+//                into registers — the reduction index may be permuted freely as long as A and B agree,
+//                so the 4 floats feed 4 consecutive 32x32x2 MFMA steps; no LDS staging, no transposition;
+//   B operand  : lane (column li, half lh) reads float4 W1[n][8q+4lh .. +3] from LDS;
+//   16 float4 of the NEXT tile replace the current ones one by one as they are consumed (rolling
+//   prefetch: a full tile of MFMA time, ~7 us, covers the load latency);
+// so the K loop has no barrier and no LDS write at all.  Epilogue as in gemm_fwd2_kernel (bias,
+// activation, hidden store, second layer by per-lane partial products and a transposing butterfly),
+// without the cross-wave combine because a wave owns all 128 columns of its rows.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// The row prefetch is written as inline assembly with hand-placed s_waitcnt: vmcnt counts loads AND
+// stores in issue order, and the compiler's own bookkeeping answers a load that is older than the
+// stores of the previous tile's epilogue with a full drain at every tile start.  The piece loaded at
+// step q of tile t is read at step q of tile t+1 with exactly KQ-1 loads and all epilogue stores
+// (>= 17 for a full tile) issued after it, so vmcnt(STREAM_VMCNT) — "all but the STREAM_VMCNT youngest
+// are done" — is always enough and never waits for more than a few of the oldest stores.
+template <int OFF>
+__device__ __forceinline__ void stream_load(f32x4& dst, const float* ptr)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void stream_wait(f32x4& v)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
+template <int F2, int KQ, int ACT1>   // KQ = K / 8: float4 pieces per lane and tile
+__global__ void __launch_bounds__(512) mlp_stream_fwd_kernel(GemmArgs p, int n_tiles)
+{
+    extern __shared__ float smem[];
+    constexpr int K = KQ * 8;
+    constexpr int LDW = K + 4;
+    constexpr int STREAM_VMCNT = KQ - 1 + 12;   // a full tile leaves 16 hidden stores + the outputs behind
+    float* Ws = smem;                       // [128][LDW]
+    float* W2s = Ws + 128 * LDW;            // [F2][128]
+    float* b1s = W2s + F2 * 128;            // [128]
+    float* b2s = b1s + 128;                 // [F2]  (a global load in the epilogue would drain every older
+                                            //        load and store of the wave: vmcnt counts in order)
+    float* stage = b2s + 8;                 // [8 waves][32][32]
+    for (int idx = threadIdx.x; idx < 128 * (K / 4); idx += 512) {
+        const int n = idx / (K / 4), k4 = (idx - n * (K / 4)) * 4;
+        const float4 q = *reinterpret_cast<const float4*>(p.B + (int64_t)n * p.ldb + k4);
+        *reinterpret_cast<float4*>(Ws + n * LDW + k4) = q;
+    }
+    for (int idx = threadIdx.x; idx < F2 * 128; idx += 512) {
+        const int o = idx >> 7, n = idx & 127;
+        W2s[idx] = o < p.f2_nout ? p.f2_W2[o * p.f2_ldw2 + n] : 0.0f;
+    }
+    if (threadIdx.x < 128) b1s[threadIdx.x] = p.bias ? p.bias[threadIdx.x] : 0.0f;
+    if (threadIdx.x < F2) b2s[threadIdx.x] = (p.f2_b2 && threadIdx.x < p.f2_nout) ? p.f2_b2[threadIdx.x] : 0.0f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int stride = gridDim.x * 8;
+    int tile = blockIdx.x * 8 + wave;
+    if (tile >= n_tiles) return;
+    f32x4 a[KQ];
+    auto row_ptr = [&](int t) {
+        int64_t r = (int64_t)t * 32 + li;
+        if (r >= p.M) r = p.M - 1;
+        return p.A + r * p.lda + 4 * lh;
+    };
+    {
+        const float* src = row_ptr(tile);
+#pragma unroll
+        for (int q = 0; q < KQ; q++) a[q] = *reinterpret_cast<const f32x4*>(src + 8 * q);   // compiler-tracked: waited for below
+    }
+    const int f2_act = p.f2_act, nout = p.f2_nout;
+    for (; tile < n_tiles; tile += stride) {
+        const int next = tile + stride;
+        const float* nsrc = row_ptr(next < n_tiles ? next : tile);
+        f32x16 acc[4];
+#pragma unroll
+        for (int tn = 0; tn < 4; tn++) {   // the accumulators start at the bias: f32 MFMAs and VALU work share the
+            const float bv = b1s[tn * 32 + li];   // SIMD's multipliers, so every VALU instruction saved is MFMA time
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[tn][r] = bv;
+        }
+        // B operands one K step ahead of the MFMAs that use them; the scheduling barriers keep the
+        // compiler from hoisting all 64+ LDS reads of the tile to the top (256 registers, spills)
+        float4 bcur[4], bnxt[4];
+#pragma unroll
+        for (int tn = 0; tn < 4; tn++) bcur[tn] = *reinterpret_cast<const float4*>(Ws + (tn * 32 + li) * LDW + 4 * lh);
+#pragma unroll
+        for (int q = 0; q < KQ; q++) {
+            stream_wait<STREAM_VMCNT>(a[q]);
+            const f32x4 av = a[q];
+            if (q + 1 < KQ) {
+#pragma unroll
+                for (int tn = 0; tn < 4; tn++)
+                    bnxt[tn] = *reinterpret_cast<const float4*>(Ws + (tn * 32 + li) * LDW + 8 * (q + 1) + 4 * lh);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int tn = 0; tn < 4; tn++) {
+                    const float bf[4] = {bcur[tn].x, bcur[tn].y, bcur[tn].z, bcur[tn].w};
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bf[j], acc[tn], 0, 0, 0);
+                }
+            }
+            switch (q) {   // the immediate offset must be a literal
+#define STREAM_CASE(Q) case Q: stream_load<32 * Q>(a[Q < KQ ? Q : 0], nsrc); break;
+                STREAM_CASE(0) STREAM_CASE(1) STREAM_CASE(2) STREAM_CASE(3) STREAM_CASE(4) STREAM_CASE(5) STREAM_CASE(6)
+                STREAM_CASE(7) STREAM_CASE(8) STREAM_CASE(9) STREAM_CASE(10) STREAM_CASE(11) STREAM_CASE(12) STREAM_CASE(13)
+                STREAM_CASE(14) STREAM_CASE(15) STREAM_CASE(16) STREAM_CASE(17) STREAM_CASE(18) STREAM_CASE(19)
+#undef STREAM_CASE
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);    // this step: the 4 LDS reads of the next step first,
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // then the 16 MFMAs (a whole step covers the LDS latency)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) bcur[tn] = bnxt[tn];
+        }
+        // ---- epilogue
+        const int64_t m0 = (int64_t)tile * 32;
+        float* stg = stage + wave * 1024;       // this wave's [32][32] transposition tile
+        constexpr int OGW = F2 < 4 ? F2 : 4;
+        constexpr int OGN = (F2 + OGW - 1) / OGW;
+#pragma unroll
+        for (int og = 0; og < OGN; og++) {
+            float part[OGW][16];
+#pragma unroll
+            for (int o = 0; o < OGW; o++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) part[o][r] = 0.0f;
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                const int n = tn * 32 + li;
+                float w2[OGW];
+#pragma unroll
+                for (int o = 0; o < OGW; o++) w2[o] = W2s[(og * OGW + o) * 128 + n];
+                if (og == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const float z = acc[tn][r];
+                        acc[tn][r] = ACT1 == NGP_ACT_RELU ? fmaxf(z, 0.0f) : (ACT1 == NGP_ACT_SOFTPLUS ? softplus_fast(z) : z);
+                    }
+                    // hidden store: 64 dword stores per lane and tile would overrun the 64 vector-memory
+                    // operations a wave may have in flight; through LDS the 32x32 block leaves as 4 x 16 bytes
+                    // per lane (rows of 128 contiguous bytes).  Both access patterns are conflict-free on an
+                    // unpadded [32][32] tile; LDS operations of one wave execute in order, so no barrier.
+#pragma unroll
+                    for (int r = 0; r < 16; r++) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[tn][r];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int f = lane + 64 * i, row = f >> 3, c4 = (f & 7) * 4;
+                        const float4 v = *reinterpret_cast<const float4*>(stg + row * 32 + c4);
+                        if (m0 + row < p.M) *reinterpret_cast<float4*>(p.C + (m0 + row) * p.ldc + tn * 32 + c4) = v;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+#pragma unroll
+                    for (int o = 0; o < OGW; o++) part[o][r] = fmaf(acc[tn][r], w2[o], part[o][r]);
+            }
+#pragma unroll
+            for (int o = 0; o < OGW; o++) {
+                float* v = part[o];
+#pragma unroll
+                for (int half = 8; half >= 1; half >>= 1) {
+                    const int mask = half * 2;   // 16, 8, 4, 2
+                    const bool up = (li & mask) != 0;
+#pragma unroll
+                    for (int j = 0; j < half; j++) {
+                        const float keep = up ? v[j + half] : v[j];
+                        const float send = up ? v[j] : v[j + half];
+                        v[j] = keep + __shfl_xor(send, mask, 64);
+                    }
+                }
+                const float tot = v[0] + __shfl_xor(v[0], 1, 64);
+                const int rr = ((li >> 4) & 1) * 8 + ((li >> 3) & 1) * 4 + ((li >> 2) & 1) * 2 + ((li >> 1) & 1);
+                const int64_t m = m0 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                const int oo = og * OGW + o;
+                if ((li & 1) == 0 && oo < nout && m < p.M)
+                    p.f2_out[m * p.f2_ldo + oo] = act_fwd(tot + b2s[oo], f2_act);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- skinny layers (n_out <= 4)
 // forward: one half-wave per sample row, each lane owns float4 pieces of the row (16-byte loads),
 // four rows per half-wave in flight, dot products reduced by xor-shuffles.
@@ -1022,6 +1210,54 @@ int ngp_mlp2_fwd(const float* x, int64_t ldx, const float* W1, int64_t ldw1, con
     p.vecA = aligned16(x) && (ldx % 4 == 0); p.vecB = aligned16(W1) && (ldw1 % 4 == 0);
     p.f2_W2 = W2; p.f2_ldw2 = ldw2; p.f2_b2 = b2; p.f2_out = out; p.f2_ldo = ldo; p.f2_nout = n_out; p.f2_act = act2;
     dim3 grid(ngp_blocks(n, 128), 1);
+    static const bool stream_ok = !getenv("NGP_MLP_NO_STREAM");
+    if (stream_ok && H == 128 && (n_in == 128 || n_in == 144 || n_in == 160) && p.vecA && p.vecB &&
+        (act1 == NGP_ACT_RELU || act1 == NGP_ACT_SOFTPLUS) && aligned16(hidden) && ldh % 4 == 0 &&
+        n <= (int64_t)32 * 0x7fffff00) {
+        // streaming kernel: W1 resident in LDS, one workgroup of 8 waves per CU, 32-row tiles per wave.
+        // Chosen by shape only, never by n: a row's result must not depend on the size of the batch it
+        // sits in (the test-time renderer's two loops are compared bit for bit)
+        const int n_tiles = (int)((n + 31) / 32);
+        const int f2 = n_out == 1 ? 1 : (n_out <= 4 ? 4 : 8);
+        const size_t lds = (size_t)(128 * (n_in + 4) + f2 * 128 + 128 + 8 + 8 * 1024) * sizeof(float);
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NGP_ELAUNCH;
+            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        const int blocks = (n_tiles + 7) / 8 < n_cu ? (n_tiles + 7) / 8 : n_cu;
+#define LAUNCH_STREAM(F2V, KQV, ACTV)                                                                                   \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream_fwd_kernel<F2V, KQV, ACTV>),              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)               \
+                return NGP_ELAUNCH;                                                                                     \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL((mlp_stream_fwd_kernel<F2V, KQV, ACTV>), dim3(blocks), dim3(512), lds, st, p, n_tiles);      \
+    } while (0)
+#define LAUNCH_STREAM_A(F2V, KQV)                                                                                       \
+    do {                                                                                                                \
+        if (act1 == NGP_ACT_RELU) LAUNCH_STREAM(F2V, KQV, NGP_ACT_RELU);                                                \
+        else LAUNCH_STREAM(F2V, KQV, NGP_ACT_SOFTPLUS);                                                                 \
+    } while (0)
+#define LAUNCH_STREAM_K(F2V)                                                                                            \
+    do {                                                                                                                \
+        if (n_in == 128) LAUNCH_STREAM_A(F2V, 16);                                                                      \
+        else if (n_in == 144) LAUNCH_STREAM_A(F2V, 18);                                                                 \
+        else LAUNCH_STREAM_A(F2V, 20);                                                                                  \
+    } while (0)
+        if (f2 == 1) LAUNCH_STREAM_K(1);
+        else if (f2 == 4) LAUNCH_STREAM_K(4);
+        else LAUNCH_STREAM_K(8);
+#undef LAUNCH_STREAM_K
+#undef LAUNCH_STREAM_A
+#undef LAUNCH_STREAM
+        return ngp_check_launch();
+    }
     if (H > 32) {
         if (n_out == 1) hipLaunchKernelGGL((gemm_fwd2_kernel<2, 2, 2, 2, 1>), grid, dim3(256), 0, st, p);
         else if (n_out <= 4) hipLaunchKernelGGL((gemm_fwd2_kernel<2, 2, 2, 2, 4>), grid, dim3(256), 0, st, p);
