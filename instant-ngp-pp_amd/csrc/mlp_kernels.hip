@@ -714,6 +714,144 @@ __global__ void __launch_bounds__(512) mlp_stream_fwd_kernel(GemmArgs p, int n_t
     }
 }
 
+// ---------------------------------------------------------------- streaming data gradient (H = n_in = 128)
+// dx = dz1 . W1 with dz1 = act1'(hidden) * (dz2 . W2) formed in registers: the same organisation as
+// mlp_stream_fwd_kernel.  W1 sits in LDS transposed ([input column][hidden unit], the reduction index
+// contiguous), a lane loads 16-byte pieces of its row of `hidden` and turns them into dz1 on the spot
+// (W2's pieces are LDS broadcasts, the row's dz2 values travel with the prefetch), the tile leaves
+// through the per-wave LDS transposition as 16-byte stores.  No epilogue arithmetic at all.
+template <int OFF>
+__device__ __forceinline__ void stream_load1(float& dst, const float* ptr)
+{
+    asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void stream_wait1(float& v)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
+template <int XF, int ACT1>
+__global__ void __launch_bounds__(512) mlp_stream_dgrad_kernel(GemmArgs p, int n_tiles)
+{
+    extern __shared__ float smem[];
+    constexpr int KQ = 16, LDW = 132;
+    constexpr int STREAM_VMCNT = KQ - 1 + 12;
+    float* Wt = smem;                       // [128 input columns][LDW]: Wt[j][n] = W1[n][j]
+    float* W2s = Wt + 128 * LDW;            // [XF][128]
+    float* stage = W2s + XF * 128;          // [8 waves][32][32]
+    for (int idx = threadIdx.x; idx < 128 * 128; idx += 512) {
+        const int n = idx >> 7, j = idx & 127;
+        Wt[j * LDW + n] = p.B[(int64_t)n * p.ldb + j];
+    }
+    for (int idx = threadIdx.x; idx < XF * 128; idx += 512) {
+        const int o = idx >> 7, n = idx & 127;
+        W2s[idx] = o < p.xf_nout ? p.xf_W2[o * p.xf_ldw2 + n] : 0.0f;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int stride = gridDim.x * 8;
+    int tile = blockIdx.x * 8 + wave;
+    if (tile >= n_tiles) return;
+    f32x4 a[KQ];
+    float d2[XF];
+    auto row_of = [&](int t) {
+        int64_t r = (int64_t)t * 32 + li;
+        return r < p.M ? r : p.M - 1;
+    };
+    {
+        const int64_t r = row_of(tile);
+        const float* src = p.A + r * p.lda + 4 * lh;
+#pragma unroll
+        for (int q = 0; q < KQ; q++) a[q] = *reinterpret_cast<const f32x4*>(src + 8 * q);
+#pragma unroll
+        for (int o = 0; o < XF; o++) d2[o] = o < p.xf_nout ? p.xf_dz2[r * p.xf_lddz2 + o] : 0.0f;
+    }
+    const int nout = p.xf_nout;
+    float* stg = stage + wave * 1024;
+    for (; tile < n_tiles; tile += stride) {
+        const int next = tile + stride;
+        const int64_t nr = row_of(next < n_tiles ? next : tile);
+        const float* nsrc = p.A + nr * p.lda + 4 * lh;
+        const float* ndz2 = p.xf_dz2 + nr * p.xf_lddz2;
+        f32x16 acc[4];
+#pragma unroll
+        for (int tn = 0; tn < 4; tn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[tn][r] = 0.0f;
+        float dcur[XF];
+#pragma unroll
+        for (int o = 0; o < XF; o++) {
+            stream_wait1<STREAM_VMCNT>(d2[o]);
+            dcur[o] = d2[o];
+        }
+        float4 bcur[4], bnxt[4];
+#pragma unroll
+        for (int tn = 0; tn < 4; tn++) bcur[tn] = *reinterpret_cast<const float4*>(Wt + (tn * 32 + li) * LDW + 4 * lh);
+#pragma unroll
+        for (int q = 0; q < KQ; q++) {
+            stream_wait<STREAM_VMCNT>(a[q]);
+            const f32x4 hv = a[q];
+            if (q + 1 < KQ) {
+#pragma unroll
+                for (int tn = 0; tn < 4; tn++)
+                    bnxt[tn] = *reinterpret_cast<const float4*>(Wt + (tn * 32 + li) * LDW + 8 * (q + 1) + 4 * lh);
+            }
+            // dz1 for this lane's 4 hidden units
+            float sv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int o = 0; o < XF; o++) {
+                const float4 w = *reinterpret_cast<const float4*>(W2s + o * 128 + 8 * q + 4 * lh);
+                sv[0] = fmaf(dcur[o], w.x, sv[0]); sv[1] = fmaf(dcur[o], w.y, sv[1]);
+                sv[2] = fmaf(dcur[o], w.z, sv[2]); sv[3] = fmaf(dcur[o], w.w, sv[3]);
+            }
+            float av[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) av[j] = sv[j] * act_grad_fast(hv[j], ACT1);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int tn = 0; tn < 4; tn++) {
+                    const float bf[4] = {bcur[tn].x, bcur[tn].y, bcur[tn].z, bcur[tn].w};
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bf[j], acc[tn], 0, 0, 0);
+                }
+            }
+            switch (q) {   // the immediate offset must be a literal
+#define STREAM_CASE(Q) case Q: stream_load<32 * Q>(a[Q], nsrc); break;
+                STREAM_CASE(0) STREAM_CASE(1) STREAM_CASE(2) STREAM_CASE(3) STREAM_CASE(4) STREAM_CASE(5) STREAM_CASE(6)
+                STREAM_CASE(7) STREAM_CASE(8) STREAM_CASE(9) STREAM_CASE(10) STREAM_CASE(11) STREAM_CASE(12) STREAM_CASE(13)
+                STREAM_CASE(14) STREAM_CASE(15)
+#undef STREAM_CASE
+            }
+            if (q == 0) {   // the next tile's dz2 values ride behind its first piece
+                if (XF > 0) stream_load1<0>(d2[0], ndz2);
+                if (XF > 1) stream_load1<4>(d2[XF > 1 ? 1 : 0], ndz2);
+                if (XF > 2) stream_load1<8>(d2[XF > 2 ? 2 : 0], ndz2);
+                if (XF > 3) stream_load1<12>(d2[XF > 3 ? 3 : 0], ndz2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) bcur[tn] = bnxt[tn];
+        }
+        // ---- store the tile through the LDS transposition (see mlp_stream_fwd_kernel)
+        const int64_t m0 = (int64_t)tile * 32;
+#pragma unroll
+        for (int tn = 0; tn < 4; tn++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[tn][r];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int f = lane + 64 * i, row = f >> 3, c4 = (f & 7) * 4;
+                const float4 v = *reinterpret_cast<const float4*>(stg + row * 32 + c4);
+                if (m0 + row < p.M) *reinterpret_cast<float4*>(p.C + (m0 + row) * p.ldc + tn * 32 + c4) = v;
+            }
+        }
+    }
+    (void)nout;
+}
+
 // ---------------------------------------------------------------- skinny layers (n_out <= 4)
 // forward: one half-wave per sample row, each lane owns float4 pieces of the row (16-byte loads),
 // four rows per half-wave in flight, dot products reduced by xor-shuffles.
@@ -1367,6 +1505,46 @@ int ngp_mlp_bwd_input(const float* dz2, int64_t lddz2, const float* W2, int64_t 
     p.M = n; p.N = n_in; p.K = H; p.accumulate = accumulate;
     p.vecA = aligned16(hidden) && (ldh % 4 == 0); p.vecB = aligned16(W1) && (ldw1 % 4 == 0);
     p.xf_dz2 = dz2; p.xf_lddz2 = lddz2; p.xf_W2 = W2; p.xf_ldw2 = ldw2; p.xf_nout = n_out; p.xf_act = act1;
+    static const bool stream_ok = !getenv("NGP_MLP_NO_STREAM");
+    if (stream_ok && H == 128 && n_in == 128 && !accumulate && p.vecA && aligned16(dx) && lddx % 4 == 0 &&
+        (act1 == NGP_ACT_RELU || act1 == NGP_ACT_SOFTPLUS) && n <= (int64_t)32 * 0x7fffff00) {
+        // streaming kernel (chosen by shape only, see ngp_mlp2_fwd); out-of-range xf_nout columns read as zero,
+        // but the dz2 prefetch reads XF floats per row: stay inside the row
+        hipStream_t st = (hipStream_t)stream;
+        const int n_tiles = (int)((n + 31) / 32);
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NGP_ELAUNCH;
+            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        const int blocks = (n_tiles + 7) / 8 < n_cu ? (n_tiles + 7) / 8 : n_cu;
+#define LAUNCH_SD(XFV, ACTV)                                                                                            \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        const size_t lds = (size_t)(128 * 132 + XFV * 128 + 8 * 1024) * sizeof(float);                                  \
+        if (!attr_set) {                                                                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream_dgrad_kernel<XFV, ACTV>),                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)              \
+                return NGP_ELAUNCH;                                                                                     \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL((mlp_stream_dgrad_kernel<XFV, ACTV>), dim3(blocks), dim3(512), lds, st, p, n_tiles);         \
+    } while (0)
+#define LAUNCH_SD_A(XFV)                                                                                                \
+    do {                                                                                                                \
+        if (act1 == NGP_ACT_RELU) LAUNCH_SD(XFV, NGP_ACT_RELU);                                                         \
+        else LAUNCH_SD(XFV, NGP_ACT_SOFTPLUS);                                                                          \
+    } while (0)
+        if (n_out == 1) LAUNCH_SD_A(1);
+        else if (n_out == 2) LAUNCH_SD_A(2);
+        else if (n_out == 3) LAUNCH_SD_A(3);
+        else LAUNCH_SD_A(4);
+#undef LAUNCH_SD_A
+#undef LAUNCH_SD
+        return ngp_check_launch();
+    }
     if (n_out == 1) launch_dgrad<1>(p, (hipStream_t)stream);
     else if (n_out <= 3) launch_dgrad<3>(p, (hipStream_t)stream);
     else launch_dgrad<XF_OMAX>(p, (hipStream_t)stream);
