@@ -852,6 +852,110 @@ __global__ void __launch_bounds__(512) mlp_stream_dgrad_kernel(GemmArgs p, int n
     (void)nout;
 }
 
+// ---------------------------------------------------------------- streaming weight gradient (H = 128)
+// dW1 (128 x n_in) += dz1^T . x over a chunk of samples per workgroup, dz1 = act1'(hidden) * (dz2 . W2).
+// Both operands are [sample][column] matrices and the reduction runs over samples, so the MFMA's
+// register layout IS the memory layout: for the step that covers samples s and s+1, lane (li, lh)
+// needs hidden[s+lh][h0+li] and x[s+lh][32 tn + li] — plain dword loads, two 128-byte row segments
+// per instruction, no LDS, no barrier, no transposition.  A wave owns 32 hidden units and ALL input
+// columns (TN = 4 or 5 accumulator blocks), so every dz1 element is formed exactly once per
+// workgroup; W2's column for the lane's hidden unit stays in registers.  The loads run D steps ahead
+// in a register ring.  Samples past the end of the chunk are read from a clamped row with dz2 = 0,
+// which zeroes dz1 and with it every contribution.  dW2 / db2 / db1 ride along as per-lane sums.
+template <int XF, int ACT1, int TN, bool W2G>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+mlp_stream_wgrad_kernel(GemmArgs p, int64_t chunk)
+{
+    constexpr int D = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t kbeg = (int64_t)blockIdx.x * chunk;
+    const int64_t kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
+    if (kbeg >= kend) return;
+    const int h = wave * 32 + li;
+    const int N = (int)p.N;
+    float w2[XF];
+#pragma unroll
+    for (int o = 0; o < XF; o++) w2[o] = p.xf_W2[o * p.xf_ldw2 + h];
+    int colc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) colc[tn] = tn * 32 + li < N ? tn * 32 + li : N - 1;   // a clamped column feeds an accumulator column that is never stored
+    f32x16 acc[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tn][r] = 0.0f;
+    float gw[XF], gb2[XF], gb1 = 0.0f;
+#pragma unroll
+    for (int o = 0; o < XF; o++) { gw[o] = 0.0f; gb2[o] = 0.0f; }
+
+    float ra[D], rb[D][TN], rd[D][XF];
+    auto issue = [&](int d, int64_t s0) {
+        const int64_t s = s0 + lh;
+        const bool ok = s < kend;
+        const int64_t sc = ok ? s : kend - 1;
+        ra[d] = p.A[sc * p.lda + h];
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++) rb[d][tn] = p.B[sc * p.ldb + colc[tn]];
+#pragma unroll
+        for (int o = 0; o < XF; o++) {
+            const float v = p.xf_dz2[sc * p.xf_lddz2 + o];
+            rd[d][o] = ok ? v : 0.0f;
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D; d++) issue(d, kbeg + 2 * d);
+    for (int64_t s0 = kbeg; s0 < kend; s0 += 2 * D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const float hid = ra[d];
+            float b[TN], dz[XF];
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) b[tn] = rb[d][tn];
+#pragma unroll
+            for (int o = 0; o < XF; o++) dz[o] = rd[d][o];
+            issue(d, s0 + 2 * d + 2 * D);
+            float sum = 0.0f;
+#pragma unroll
+            for (int o = 0; o < XF; o++) sum = fmaf(dz[o], w2[o], sum);
+            const float a = sum * act_grad_fast(hid, ACT1);
+            if (W2G) {
+#pragma unroll
+                for (int o = 0; o < XF; o++) {
+                    gw[o] = fmaf(dz[o], hid, gw[o]);
+                    gb2[o] += dz[o];
+                }
+            }
+            gb1 += a;
+#pragma unroll
+            for (int tn = 0; tn < TN; tn++) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[tn], acc[tn], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+        const int col = tn * 32 + li;
+        if (col < N) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                atomicAdd(p.C + (int64_t)row * p.ldc + col, acc[tn][r]);
+            }
+        }
+    }
+    // per-lane sums: the two sample parities (lh) meet, lanes 0..31 carry hidden unit h
+    gb1 += __shfl_xor(gb1, 32, 64);
+    if (p.bias_grad && lh == 0) atomicAdd(p.bias_grad + h, gb1);
+    if (W2G && p.xf_dW2) {
+#pragma unroll
+        for (int o = 0; o < XF; o++) {
+            const float t = gw[o] + __shfl_xor(gw[o], 32, 64);
+            if (lh == 0 && o < p.xf_nout) atomicAdd(p.xf_dW2 + o * p.xf_lddw2 + h, t);
+            const float t2 = gb2[o] + __shfl_xor(gb2[o], 32, 64);   // every lane of a half holds the same sum
+            if (p.xf_db2 && wave == 0 && lane == 0 && o < p.xf_nout) atomicAdd(p.xf_db2 + o, t2);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- skinny layers (n_out <= 4)
 // forward: one half-wave per sample row, each lane owns float4 pieces of the row (16-byte loads),
 // four rows per half-wave in flight, dot products reduced by xor-shuffles.
@@ -1566,6 +1670,46 @@ int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t
     p.vecA = aligned16(hidden) && (ldh % 4 == 0); p.vecB = aligned16(x) && (ldx % 4 == 0);
     p.xf_dz2 = dz2; p.xf_lddz2 = lddz2; p.xf_W2 = W2; p.xf_ldw2 = ldw2; p.xf_nout = n_out; p.xf_act = act1;
     p.xf_dW2 = dW2; p.xf_lddw2 = lddw2; p.xf_db2 = db2;
+    static const bool stream_ok = !getenv("NGP_MLP_NO_STREAM") && !getenv("NGP_MLP_NO_STREAM_WGRAD");
+    if (stream_ok && H == 128 && (n_in == 128 || n_in == 144 || n_in == 160) &&
+        (act1 == NGP_ACT_RELU || act1 == NGP_ACT_SOFTPLUS)) {
+        hipStream_t st = (hipStream_t)stream;
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NGP_ELAUNCH;
+            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        // one round of workgroups (2 per CU); chunks are multiples of the 16 samples one ring turn covers
+        int64_t blocks = 2 * (int64_t)n_cu;
+        int64_t chunk = ((n + blocks - 1) / blocks + 15) / 16 * 16;
+        if (chunk < 64) chunk = 64;
+        blocks = (n + chunk - 1) / chunk;
+#define LAUNCH_SW(XFV, ACTV, TNV)                                                                                       \
+    do {                                                                                                                \
+        if (dW2) hipLaunchKernelGGL((mlp_stream_wgrad_kernel<XFV, ACTV, TNV, true>), dim3((unsigned)blocks), dim3(256), 0, st, p, chunk);  \
+        else hipLaunchKernelGGL((mlp_stream_wgrad_kernel<XFV, ACTV, TNV, false>), dim3((unsigned)blocks), dim3(256), 0, st, p, chunk);     \
+    } while (0)
+#define LAUNCH_SW_T(XFV, ACTV)                                                                                          \
+    do {                                                                                                                \
+        if (n_in == 128) LAUNCH_SW(XFV, ACTV, 4);                                                                       \
+        else LAUNCH_SW(XFV, ACTV, 5);                                                                                   \
+    } while (0)
+#define LAUNCH_SW_A(XFV)                                                                                                \
+    do {                                                                                                                \
+        if (act1 == NGP_ACT_RELU) LAUNCH_SW_T(XFV, NGP_ACT_RELU);                                                       \
+        else LAUNCH_SW_T(XFV, NGP_ACT_SOFTPLUS);                                                                        \
+    } while (0)
+        if (n_out == 1) LAUNCH_SW_A(1);
+        else if (n_out == 2) LAUNCH_SW_A(2);
+        else if (n_out == 3) LAUNCH_SW_A(3);
+        else LAUNCH_SW_A(4);
+#undef LAUNCH_SW_A
+#undef LAUNCH_SW_T
+#undef LAUNCH_SW
+        return ngp_check_launch();
+    }
     if (n_out == 1) launch_wgrad<1>(p, (hipStream_t)stream);
     else if (n_out <= 3) launch_wgrad<3>(p, (hipStream_t)stream);
     else launch_wgrad<XF_OMAX>(p, (hipStream_t)stream);

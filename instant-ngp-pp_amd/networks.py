@@ -77,6 +77,8 @@ import os as _os
 _OVERLAP = _os.environ.get("NGP_NO_OVERLAP", "0") != "1"
 _FUSED_FWD = _os.environ.get("NGP_NO_FUSED_FWD", "0") != "1"   # A/B switch for ngp_mlp2_fwd
 _FUSED_BWD = _os.environ.get("NGP_NO_FUSED_BWD", "0") != "1"   # A/B switch for the operand-transform products
+# the library's streaming weight-gradient kernel (mlp_stream_wgrad_kernel) is on unless one of its A/B switches is set
+_STREAM_WGRAD = not (_os.environ.get("NGP_MLP_NO_STREAM") or _os.environ.get("NGP_MLP_NO_STREAM_WGRAD"))
 # widest second layer that takes the fused route (tools/mlp_bwd_microbench.py, n = 433 k, MI355X):
 # density head 0.54 -> 0.49 ms, rgb_net 0.60 -> 0.57 ms, 32-wide headers 0.22 -> 0.22 ms
 _FUSED_BWD_MAX_OUT = int(_os.environ.get("NGP_FUSED_BWD_MAX_OUT", "3"))
@@ -112,7 +114,11 @@ def _mlp2_backward(d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, l
         if before_products is not None:
             before_products()
         # the first-layer weight product streams dz2 and hidden anyway: it also leaves dW2 / db2
-        if wide:
+        if wide and _STREAM_WGRAD and H == 128 and n_in in (144, 160) and act1 in (_RELU, _SOFTPLUS):
+            # the streaming kernel takes all 144 / 160 input columns (and dW2 / db2) in one pass
+            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, n_in, H, n_out, dW1, ldw1, db1,
+                 dW2, H, db2)
+        elif wide:
             # dW2 / db2 ride with the narrow remainder launch (16 accumulator registers per lane; in the
             # 128x128 one the extra partial sums would spill at 3 workgroups per CU)
             call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, 128, H, n_out, dW1, ldw1, db1,
