@@ -863,23 +863,30 @@ __global__ void __launch_bounds__(512) mlp_stream_dgrad_kernel(GemmArgs p, int n
 // in a register ring.  Samples past the end of the chunk are read from a clamped row with dz2 = 0,
 // which zeroes dz1 and with it every contribution.  dW2 / db2 / db1 ride along as per-lane sums.
 template <int XF, int ACT1, int TN, bool W2G>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
-mlp_stream_wgrad_kernel(GemmArgs p, int64_t chunk)
+__global__ void __launch_bounds__(512) mlp_stream_wgrad_kernel(GemmArgs p, int64_t chunk)
 {
+    // 8 waves: two groups of 4 (one per 32 hidden units) split the workgroup's chunk of samples in halves and
+    // meet in LDS before the atomics — the 128 x n_in atomic adds per workgroup are a fixed cost (~55 us
+    // per launch with two 4-wave workgroups per CU), one 8-wave workgroup per CU halves it at the same occupancy
+    extern __shared__ float lds[];
     constexpr int D = 8;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, grp = threadIdx.x >> 8;
     const int li = lane & 31, lh = lane >> 5;
-    const int64_t kbeg = (int64_t)blockIdx.x * chunk;
-    const int64_t kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
-    if (kbeg >= kend) return;
+    const bool two = blockDim.x == 512;                  // launched with 4 waves instead: one group, no hand-over
+    const int64_t half = two ? chunk / 2 : chunk;        // chunk is a multiple of 32
+    const int64_t cbeg = (int64_t)blockIdx.x * chunk;    // the workgroup's chunk is never empty (launch geometry)
+    const int64_t cend = cbeg + chunk < p.K ? cbeg + chunk : p.K;
+    const int64_t kbeg = cbeg + grp * half < cend ? cbeg + grp * half : cend;
+    const int64_t kend = grp == 0 ? (cbeg + half < cend ? cbeg + half : cend) : cend;
     const int h = wave * 32 + li;
     const int N = (int)p.N;
     float w2[XF];
 #pragma unroll
     for (int o = 0; o < XF; o++) w2[o] = p.xf_W2[o * p.xf_ldw2 + h];
-    int colc[TN];
-#pragma unroll
-    for (int tn = 0; tn < TN; tn++) colc[tn] = tn * 32 + li < N ? tn * 32 + li : N - 1;   // a clamped column feeds an accumulator column that is never stored
+    // input columns of the lane: 4 li .. 4 li + 3 for the first four accumulator blocks (ONE 16-byte load per
+    // sample instead of four dwords; which column a lane's accumulator stands for is free to choose),
+    // 128 + li for the fifth (clamped: a clamped column feeds an accumulator column that is never stored)
+    const int col5 = 128 + li < N ? 128 + li : N - 1;
     f32x16 acc[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; tn++)
@@ -889,29 +896,33 @@ mlp_stream_wgrad_kernel(GemmArgs p, int64_t chunk)
 #pragma unroll
     for (int o = 0; o < XF; o++) { gw[o] = 0.0f; gb2[o] = 0.0f; }
 
-    float ra[D], rb[D][TN], rd[D][XF];
+    float ra[D], rb5[D], rd[D][XF];
+    f32x4 rb[D];
     auto issue = [&](int d, int64_t s0) {
         const int64_t s = s0 + lh;
         const bool ok = s < kend;
         const int64_t sc = ok ? s : kend - 1;
         ra[d] = p.A[sc * p.lda + h];
-#pragma unroll
-        for (int tn = 0; tn < TN; tn++) rb[d][tn] = p.B[sc * p.ldb + colc[tn]];
+        rb[d] = *reinterpret_cast<const f32x4*>(p.B + sc * p.ldb + 4 * li);
+        if (TN > 4) rb5[d] = p.B[sc * p.ldb + col5];
 #pragma unroll
         for (int o = 0; o < XF; o++) {
             const float v = p.xf_dz2[sc * p.xf_lddz2 + o];
             rd[d][o] = ok ? v : 0.0f;
         }
     };
+    if (kbeg < kend) {
 #pragma unroll
-    for (int d = 0; d < D; d++) issue(d, kbeg + 2 * d);
+        for (int d = 0; d < D; d++) issue(d, kbeg + 2 * d);
+    }
     for (int64_t s0 = kbeg; s0 < kend; s0 += 2 * D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const float hid = ra[d];
             float b[TN], dz[XF];
 #pragma unroll
-            for (int tn = 0; tn < TN; tn++) b[tn] = rb[d][tn];
+            for (int tn = 0; tn < 4; tn++) b[tn] = rb[d][tn];
+            if (TN > 4) b[TN - 1] = rb5[d];
 #pragma unroll
             for (int o = 0; o < XF; o++) dz[o] = rd[d][o];
             issue(d, s0 + 2 * d + 2 * D);
@@ -931,14 +942,55 @@ mlp_stream_wgrad_kernel(GemmArgs p, int64_t chunk)
             for (int tn = 0; tn < TN; tn++) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[tn], acc[tn], 0, 0, 0);
         }
     }
+    // ---- the second group hands its sums to the first, lane for lane
+    if (two) {
+        float* comb = lds + (wave * (TN * 16 + 2 * XF + 1)) * 64 + lane;
+        if (grp == 1) {
 #pragma unroll
-    for (int tn = 0; tn < TN; tn++) {
-        const int col = tn * 32 + li;
+            for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) comb[(tn * 16 + r) * 64] = acc[tn][r];
+#pragma unroll
+            for (int o = 0; o < XF; o++) { comb[(TN * 16 + o) * 64] = gw[o]; comb[(TN * 16 + XF + o) * 64] = gb2[o]; }
+            comb[(TN * 16 + 2 * XF) * 64] = gb1;
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[tn][r] += comb[(tn * 16 + r) * 64];
+#pragma unroll
+        for (int o = 0; o < XF; o++) { gw[o] += comb[(TN * 16 + o) * 64]; gb2[o] += comb[(TN * 16 + XF + o) * 64]; }
+        gb1 += comb[(TN * 16 + 2 * XF) * 64];
+    }
+    // The lane's four accumulator blocks stand for ADJACENT columns: straight atomics would touch 16-byte
+    // pieces 64 bytes apart.  Half a tile at a time (16 rows) goes through LDS and leaves as atomics on
+    // 256 contiguous bytes per instruction.  (A wave only touches its own slice of `lds` from here on, and
+    // that slice lies inside the region it alone read above.)
+    float (*wstage)[128] = reinterpret_cast<float (*)[128]>(lds + wave * (two ? (TN * 16 + 2 * XF + 1) * 64 : 2048));
+#pragma unroll
+    for (int half2 = 0; half2 < 2; half2++) {
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++) {
+            const int r = half2 * 8 + rr;
+            const int row16 = (rr & 3) + 8 * (rr >> 2) + 4 * lh;        // row inside the 16-row half
+            const float4 v = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            *reinterpret_cast<float4*>(&wstage[row16][4 * li]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int flat = i * 64 + lane, row16 = flat >> 7, col = flat & 127;
+            atomicAdd(p.C + (int64_t)(wave * 32 + half2 * 16 + row16) * p.ldc + col, wstage[row16][col]);
+        }
+    }
+    if (TN > 4) {
+        const int col = 128 + li;
         if (col < N) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                atomicAdd(p.C + (int64_t)row * p.ldc + col, acc[tn][r]);
+                atomicAdd(p.C + (int64_t)row * p.ldc + col, acc[TN - 1][r]);
             }
         }
     }
@@ -1671,7 +1723,7 @@ int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t
     p.xf_dz2 = dz2; p.xf_lddz2 = lddz2; p.xf_W2 = W2; p.xf_ldw2 = ldw2; p.xf_nout = n_out; p.xf_act = act1;
     p.xf_dW2 = dW2; p.xf_lddw2 = lddw2; p.xf_db2 = db2;
     static const bool stream_ok = !getenv("NGP_MLP_NO_STREAM") && !getenv("NGP_MLP_NO_STREAM_WGRAD");
-    if (stream_ok && H == 128 && (n_in == 128 || n_in == 144 || n_in == 160) &&
+    if (stream_ok && H == 128 && (n_in == 128 || n_in == 144 || n_in == 160) && p.vecB &&
         (act1 == NGP_ACT_RELU || act1 == NGP_ACT_SOFTPLUS)) {
         hipStream_t st = (hipStream_t)stream;
         static int n_cu = 0;
@@ -1681,15 +1733,32 @@ int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t
             if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NGP_ELAUNCH;
             n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
-        // one round of workgroups (2 per CU); chunks are multiples of the 16 samples one ring turn covers
-        int64_t blocks = 2 * (int64_t)n_cu;
-        int64_t chunk = ((n + blocks - 1) / blocks + 15) / 16 * 16;
-        if (chunk < 64) chunk = 64;
+        // 8 waves per CU either way: one workgroup of 8 (two groups meeting in LDS, half the atomics) for the
+        // 128-column case, two workgroups of 4 for the 144 / 160-column case (measured: 0.236 -> 0.225 ms and
+        // 0.313 -> 0.331 ms respectively with 8); a group's share of the chunk is a multiple of the 16 samples
+        // one turn of the prefetch ring covers
+        const int threads = n_in == 128 ? 512 : 256;
+        int64_t blocks = (int64_t)n_cu * (threads == 512 ? 1 : 2);
+        int64_t chunk = ((n + blocks - 1) / blocks + 31) / 32 * 32;
+        if (chunk < 128) chunk = 128;
         blocks = (n + chunk - 1) / chunk;
+#define LAUNCH_SW2(XFV, ACTV, TNV, W2GV)                                                                                \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        const size_t lds = (size_t)4 * (threads == 512 ? (TNV * 16 + 2 * XFV + 1) * 64 : 2048) * sizeof(float);         \
+        if (!attr_set) {                                                                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream_wgrad_kernel<XFV, ACTV, TNV, W2GV>),      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)               \
+                return NGP_ELAUNCH;                                                                                     \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL((mlp_stream_wgrad_kernel<XFV, ACTV, TNV, W2GV>), dim3((unsigned)blocks), dim3(threads), lds, st, \
+                           p, chunk);                                                                                   \
+    } while (0)
 #define LAUNCH_SW(XFV, ACTV, TNV)                                                                                       \
     do {                                                                                                                \
-        if (dW2) hipLaunchKernelGGL((mlp_stream_wgrad_kernel<XFV, ACTV, TNV, true>), dim3((unsigned)blocks), dim3(256), 0, st, p, chunk);  \
-        else hipLaunchKernelGGL((mlp_stream_wgrad_kernel<XFV, ACTV, TNV, false>), dim3((unsigned)blocks), dim3(256), 0, st, p, chunk);     \
+        if (dW2) LAUNCH_SW2(XFV, ACTV, TNV, true);                                                                      \
+        else LAUNCH_SW2(XFV, ACTV, TNV, false);                                                                         \
     } while (0)
 #define LAUNCH_SW_T(XFV, ACTV)                                                                                          \
     do {                                                                                                                \
@@ -1708,6 +1777,7 @@ int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t
 #undef LAUNCH_SW_A
 #undef LAUNCH_SW_T
 #undef LAUNCH_SW
+#undef LAUNCH_SW2
         return ngp_check_launch();
     }
     if (n_out == 1) launch_wgrad<1>(p, (hipStream_t)stream);
