@@ -559,29 +559,30 @@ __device__ __forceinline__ void stream_wait(f32x4& v)
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
 }
 
-template <int F2, int KQ, int ACT1>   // KQ = K / 8: float4 pieces per lane and tile
+template <int F2, int KQ, int ACT1, int TN>   // KQ = K / 8: float4 pieces per lane and tile; TN = H / 32 column blocks
 __global__ void __launch_bounds__(512) mlp_stream_fwd_kernel(GemmArgs p, int n_tiles)
 {
     extern __shared__ float smem[];
     constexpr int K = KQ * 8;
     constexpr int LDW = K + 4;
-    constexpr int STREAM_VMCNT = KQ - 1 + 12;   // a full tile leaves 16 hidden stores + the outputs behind
-    float* Ws = smem;                       // [128][LDW]
-    float* W2s = Ws + 128 * LDW;            // [F2][128]
-    float* b1s = W2s + F2 * 128;            // [128]
-    float* b2s = b1s + 128;                 // [F2]  (a global load in the epilogue would drain every older
+    constexpr int STREAM_VMCNT = KQ - 1 + 4 * TN - 4;   // a full tile leaves 4 TN hidden stores + the outputs behind
+    constexpr int H = 32 * TN;
+    float* Ws = smem;                       // [H][LDW]
+    float* W2s = Ws + H * LDW;              // [F2][H]
+    float* b1s = W2s + F2 * H;              // [H]
+    float* b2s = b1s + H;                   // [F2]  (a global load in the epilogue would drain every older
                                             //        load and store of the wave: vmcnt counts in order)
     float* stage = b2s + 8;                 // [8 waves][32][32]
-    for (int idx = threadIdx.x; idx < 128 * (K / 4); idx += 512) {
+    for (int idx = threadIdx.x; idx < H * (K / 4); idx += 512) {
         const int n = idx / (K / 4), k4 = (idx - n * (K / 4)) * 4;
         const float4 q = *reinterpret_cast<const float4*>(p.B + (int64_t)n * p.ldb + k4);
         *reinterpret_cast<float4*>(Ws + n * LDW + k4) = q;
     }
-    for (int idx = threadIdx.x; idx < F2 * 128; idx += 512) {
-        const int o = idx >> 7, n = idx & 127;
+    for (int idx = threadIdx.x; idx < F2 * H; idx += 512) {
+        const int o = idx / H, n = idx - o * H;
         W2s[idx] = o < p.f2_nout ? p.f2_W2[o * p.f2_ldw2 + n] : 0.0f;
     }
-    if (threadIdx.x < 128) b1s[threadIdx.x] = p.bias ? p.bias[threadIdx.x] : 0.0f;
+    if (threadIdx.x < H) b1s[threadIdx.x] = p.bias ? p.bias[threadIdx.x] : 0.0f;
     if (threadIdx.x < F2) b2s[threadIdx.x] = (p.f2_b2 && threadIdx.x < p.f2_nout) ? p.f2_b2[threadIdx.x] : 0.0f;
     __syncthreads();
 
@@ -605,31 +606,31 @@ __global__ void __launch_bounds__(512) mlp_stream_fwd_kernel(GemmArgs p, int n_t
     for (; tile < n_tiles; tile += stride) {
         const int next = tile + stride;
         const float* nsrc = row_ptr(next < n_tiles ? next : tile);
-        f32x16 acc[4];
+        f32x16 acc[TN];
 #pragma unroll
-        for (int tn = 0; tn < 4; tn++) {   // the accumulators start at the bias: f32 MFMAs and VALU work share the
+        for (int tn = 0; tn < TN; tn++) {   // the accumulators start at the bias: f32 MFMAs and VALU work share the
             const float bv = b1s[tn * 32 + li];   // SIMD's multipliers, so every VALU instruction saved is MFMA time
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[tn][r] = bv;
         }
         // B operands one K step ahead of the MFMAs that use them; the scheduling barriers keep the
         // compiler from hoisting all 64+ LDS reads of the tile to the top (256 registers, spills)
-        float4 bcur[4], bnxt[4];
+        float4 bcur[TN], bnxt[TN];
 #pragma unroll
-        for (int tn = 0; tn < 4; tn++) bcur[tn] = *reinterpret_cast<const float4*>(Ws + (tn * 32 + li) * LDW + 4 * lh);
+        for (int tn = 0; tn < TN; tn++) bcur[tn] = *reinterpret_cast<const float4*>(Ws + (tn * 32 + li) * LDW + 4 * lh);
 #pragma unroll
         for (int q = 0; q < KQ; q++) {
             stream_wait<STREAM_VMCNT>(a[q]);
             const f32x4 av = a[q];
             if (q + 1 < KQ) {
 #pragma unroll
-                for (int tn = 0; tn < 4; tn++)
+                for (int tn = 0; tn < TN; tn++)
                     bnxt[tn] = *reinterpret_cast<const float4*>(Ws + (tn * 32 + li) * LDW + 8 * (q + 1) + 4 * lh);
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
 #pragma unroll
-                for (int tn = 0; tn < 4; tn++) {
+                for (int tn = 0; tn < TN; tn++) {
                     const float bf[4] = {bcur[tn].x, bcur[tn].y, bcur[tn].z, bcur[tn].w};
                     acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bf[j], acc[tn], 0, 0, 0);
                 }
@@ -645,7 +646,7 @@ __global__ void __launch_bounds__(512) mlp_stream_fwd_kernel(GemmArgs p, int n_t
             __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // then the 16 MFMAs (a whole step covers the LDS latency)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tn = 0; tn < 4; tn++) bcur[tn] = bnxt[tn];
+            for (int tn = 0; tn < TN; tn++) bcur[tn] = bnxt[tn];
         }
         // ---- epilogue
         const int64_t m0 = (int64_t)tile * 32;
@@ -660,11 +661,11 @@ __global__ void __launch_bounds__(512) mlp_stream_fwd_kernel(GemmArgs p, int n_t
 #pragma unroll
                 for (int r = 0; r < 16; r++) part[o][r] = 0.0f;
 #pragma unroll
-            for (int tn = 0; tn < 4; tn++) {
+            for (int tn = 0; tn < TN; tn++) {
                 const int n = tn * 32 + li;
                 float w2[OGW];
 #pragma unroll
-                for (int o = 0; o < OGW; o++) w2[o] = W2s[(og * OGW + o) * 128 + n];
+                for (int o = 0; o < OGW; o++) w2[o] = W2s[(og * OGW + o) * H + n];
                 if (og == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
@@ -1505,15 +1506,19 @@ int ngp_mlp2_fwd(const float* x, int64_t ldx, const float* W1, int64_t ldw1, con
     p.f2_W2 = W2; p.f2_ldw2 = ldw2; p.f2_b2 = b2; p.f2_out = out; p.f2_ldo = ldo; p.f2_nout = n_out; p.f2_act = act2;
     dim3 grid(ngp_blocks(n, 128), 1);
     static const bool stream_ok = !getenv("NGP_MLP_NO_STREAM");
-    if (stream_ok && H == 128 && (n_in == 128 || n_in == 144 || n_in == 160) && p.vecA && p.vecB &&
+    const bool wide_ok = H == 128 && (n_in == 128 || n_in == 144 || n_in == 160);
+    // the 32-wide heads are HBM-bound either way (0.062 ms streaming, 0.060 ms tiled): opt-in only
+    static const bool stream_heads = getenv("NGP_MLP_STREAM_HEADS") != nullptr;
+    const bool head_ok = stream_heads && H == 32 && n_in == 128;
+    if (stream_ok && (wide_ok || head_ok) && p.vecA && p.vecB &&
         (act1 == NGP_ACT_RELU || act1 == NGP_ACT_SOFTPLUS) && aligned16(hidden) && ldh % 4 == 0 &&
         n <= (int64_t)32 * 0x7fffff00) {
-        // streaming kernel: W1 resident in LDS, one workgroup of 8 waves per CU, 32-row tiles per wave.
+        // streaming kernel: W1 resident in LDS, workgroups of 8 waves, 32-row tiles per wave.
         // Chosen by shape only, never by n: a row's result must not depend on the size of the batch it
         // sits in (the test-time renderer's two loops are compared bit for bit)
         const int n_tiles = (int)((n + 31) / 32);
         const int f2 = n_out == 1 ? 1 : (n_out <= 4 ? 4 : 8);
-        const size_t lds = (size_t)(128 * (n_in + 4) + f2 * 128 + 128 + 8 + 8 * 1024) * sizeof(float);
+        const size_t lds = (size_t)(H * (n_in + 4) + f2 * H + H + 8 + 8 * 1024) * sizeof(float);
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
@@ -1521,28 +1526,31 @@ int ngp_mlp2_fwd(const float* x, int64_t ldx, const float* W1, int64_t ldw1, con
             if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NGP_ELAUNCH;
             n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
-        const int blocks = (n_tiles + 7) / 8 < n_cu ? (n_tiles + 7) / 8 : n_cu;
-#define LAUNCH_STREAM(F2V, KQV, ACTV)                                                                                   \
+        // one workgroup per CU for the 128-wide layers (W1 takes half the LDS), two for the 32-wide heads
+        const int max_blocks = n_cu * (H == 128 ? 1 : 2);
+        const int blocks = (n_tiles + 7) / 8 < max_blocks ? (n_tiles + 7) / 8 : max_blocks;
+#define LAUNCH_STREAM(F2V, KQV, ACTV, TNV)                                                                              \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream_fwd_kernel<F2V, KQV, ACTV>),              \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)               \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream_fwd_kernel<F2V, KQV, ACTV, TNV>),         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)              \
                 return NGP_ELAUNCH;                                                                                     \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL((mlp_stream_fwd_kernel<F2V, KQV, ACTV>), dim3(blocks), dim3(512), lds, st, p, n_tiles);      \
+        hipLaunchKernelGGL((mlp_stream_fwd_kernel<F2V, KQV, ACTV, TNV>), dim3(blocks), dim3(512), lds, st, p, n_tiles); \
     } while (0)
-#define LAUNCH_STREAM_A(F2V, KQV)                                                                                       \
+#define LAUNCH_STREAM_A(F2V, KQV, TNV)                                                                                  \
     do {                                                                                                                \
-        if (act1 == NGP_ACT_RELU) LAUNCH_STREAM(F2V, KQV, NGP_ACT_RELU);                                                \
-        else LAUNCH_STREAM(F2V, KQV, NGP_ACT_SOFTPLUS);                                                                 \
+        if (act1 == NGP_ACT_RELU) LAUNCH_STREAM(F2V, KQV, NGP_ACT_RELU, TNV);                                           \
+        else LAUNCH_STREAM(F2V, KQV, NGP_ACT_SOFTPLUS, TNV);                                                            \
     } while (0)
 #define LAUNCH_STREAM_K(F2V)                                                                                            \
     do {                                                                                                                \
-        if (n_in == 128) LAUNCH_STREAM_A(F2V, 16);                                                                      \
-        else if (n_in == 144) LAUNCH_STREAM_A(F2V, 18);                                                                 \
-        else LAUNCH_STREAM_A(F2V, 20);                                                                                  \
+        if (H == 32) LAUNCH_STREAM_A(F2V, 16, 1);                                                                       \
+        else if (n_in == 128) LAUNCH_STREAM_A(F2V, 16, 4);                                                              \
+        else if (n_in == 144) LAUNCH_STREAM_A(F2V, 18, 4);                                                              \
+        else LAUNCH_STREAM_A(F2V, 20, 4);                                                                               \
     } while (0)
         if (f2 == 1) LAUNCH_STREAM_K(1);
         else if (f2 == 4) LAUNCH_STREAM_K(4);

@@ -589,6 +589,55 @@ def test_sumsq_and_clip_coef(ngp, n):
 
 
 @pytest.mark.parametrize("case", [
+    # n_in, n_out, act1 (hidden), biases
+    (128, 1, 3, True),      # xyz_net
+    (144, 3, 1, False),     # rgb_net
+    (160, 7, 1, False),     # rgb_net with appearance codes, two epilogue passes
+])
+def test_streaming_mlp_kernels_many_tiles(ngp, case):
+    """The streaming kernels of the 128-wide layers (mlp_stream_fwd / dgrad / wgrad) at a size where every
+    wave walks several tiles — the rolling row prefetch with its hand-placed vmcnt waits, the register
+    ring of the weight gradient, the clamped / zeroed tail of the last chunk — against fp64 on EVERY row."""
+    from ngp_amd._lib import call
+    n_in, n_out, act1, biases = case
+    n, H = 150001, 128
+    gen = torch.Generator(device=DEV).manual_seed(700 + n_in)
+    x = torch.randn(n, n_in, device=DEV, generator=gen)
+    W1 = torch.randn(H, n_in, device=DEV, generator=gen) * 0.1
+    W2 = torch.randn(n_out, H, device=DEV, generator=gen) * 0.1
+    b1 = torch.randn(H, device=DEV, generator=gen) * 0.1 if biases else None
+    b2 = torch.randn(n_out, device=DEV, generator=gen) * 0.1 if biases else None
+    f1 = (lambda v: torch.relu(v)) if act1 == 1 else (lambda v: torch.nn.functional.softplus(v))
+    hidden = torch.full((n, H), float("nan"), device=DEV)
+    out = torch.full((n, n_out), float("nan"), device=DEV)
+    call("mlp2_fwd", x, n_in, W1, n_in, b1, act1, W2, H, b2, 0, n, n_in, H, n_out, hidden, H, out, n_out)
+    z1 = x.double() @ W1.double().T + (0 if b1 is None else b1.double())
+    h64 = f1(z1)
+    o64 = h64 @ W2.double().T + (0 if b2 is None else b2.double())
+    assert float((hidden.double() - h64).abs().max()) < 2e-5
+    assert float((out.double() - o64).abs().max()) < 2e-5
+    # backward products from the stored hidden activations
+    n_o = min(n_out, 4)                               # the operand-transform kernels take up to 4 outputs
+    dz2 = torch.randn(n, n_o, device=DEV, generator=gen)
+    W2b = W2[:n_o].contiguous()
+    g64 = (hidden.double() > 0).double() if act1 == 1 else -torch.expm1(-hidden.double())
+    dz1 = (dz2.double() @ W2b.double()) * g64
+    dx = torch.full((n, 128), float("nan"), device=DEV)
+    W1c = W1[:, n_in - 128:]                          # gradient w.r.t. the last 128 input columns (ld = n_in), as the field asks
+    call("mlp_bwd_input", dz2, n_o, W2b, H, hidden, H, act1, W1c, n_in, n, 128, H, n_o, dx, 128, 0)
+    ref_dx = dz1 @ W1c.double()
+    assert float((dx.double() - ref_dx).abs().max()) < 2e-5 * max(1.0, float(ref_dx.abs().max()))
+    dW1 = torch.zeros(H, n_in, device=DEV)
+    dW2 = torch.zeros(n_o, H, device=DEV)
+    db1 = torch.zeros(H, device=DEV) if biases else None
+    db2 = torch.zeros(n_o, device=DEV) if biases else None
+    call("mlp_bwd_weight", dz2, n_o, W2b, H, hidden, H, act1, x, n_in, n, n_in, H, n_o, dW1, n_in, db1, dW2, H, db2)
+    for got, ref in ((dW1, dz1.T @ x.double()), (dW2, dz2.double().T @ hidden.double())) + \
+            (((db1, dz1.sum(0)), (db2, dz2.double().sum(0))) if biases else ()):
+        assert float((got.double() - ref).abs().max()) < 5e-6 * float(ref.abs().max()) + 1e-6, (got.shape,)
+
+
+@pytest.mark.parametrize("case", [
     # n, H, n_in, n_out, act1
     (1000, 128, 128, 1, 3),     # density head: softplus hidden, one output
     (1531, 128, 144, 3, 1),     # rgb_net: ReLU hidden, 144 (not a multiple of the tile) inputs
