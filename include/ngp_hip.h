@@ -20,7 +20,7 @@
  *   - empty batches (n == 0) are valid and return NGP_OK before any pointer is looked at;
  *   - a few NGP_* environment variables, read once, select older kernel variants for A/B timing
  *     (NGP_GRID_BWD_SIMPLE / _NOPAIR / _NOSLIDE, NGP_MARCH_LANE_PER_RAY, NGP_ADAM_BLOCKS,
- *     NGP_WGRAD_BLOCKS, NGP_MLP_NO_STREAM, NGP_MLP_NO_STREAM_WGRAD); results are the same up to summation order.
+ *     NGP_WGRAD_BLOCKS, NGP_MLP_NO_STREAM, NGP_MLP_NO_STREAM_WGRAD, NGP_ADAM_DENSE_ZERO); results are the same up to summation order.
  *
  * Each entry point cites the reference interface it replaces.
  */

@@ -1295,7 +1295,7 @@ __global__ void __launch_bounds__(256) mlp_hidden_bwd_kernel(const float* __rest
 // ---------------------------------------------------------------- optimizer
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             int64_t n, float step_size, float beta1, float beta2, float eps, float bc2_sqrt,
-                            float weight_decay, const float* __restrict__ grad_scale, int zero_grad)
+                            float weight_decay, const float* __restrict__ grad_scale, int zero_grad, bool sparse_zero)
 {
     const float gs = grad_scale ? *grad_scale : 1.0f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1315,6 +1315,7 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
         }
     };
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto nz = [](const float4& q) { return q.x != 0.0f || q.y != 0.0f || q.z != 0.0f || q.w != 0.0f; };
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // two independent 16-B quads per lane and trip: the launch is capped well below full occupancy
     // (other streams' kernels must be able to get wave slots), so the bytes in flight come from
@@ -1327,13 +1328,15 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
         update(pb, gb, mb, vb);
         p4[i] = pa; m4[i] = ma; v4[i] = va;
         p4[k] = pb; m4[k] = mb; v4[k] = vb;
-        if (zero_grad) { g4[i] = zero4; g4[k] = zero4; }
+        // untouched table rows (no sample near them this step) already hold zeros: do not write them again
+        if (zero_grad && (sparse_zero ? nz(ga) : true)) g4[i] = zero4;
+        if (zero_grad && (sparse_zero ? nz(gb) : true)) g4[k] = zero4;
     }
     for (; i < n4; i += stride) {
         float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
         update(pp, gg, mm, vv);
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
-        if (zero_grad) g4[i] = zero4;
+        if (zero_grad && (sparse_zero ? nz(gg) : true)) g4[i] = zero4;
     }
     // tail
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -1814,8 +1817,10 @@ int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
     int64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > cap) blocks = cap;
+    static const bool sparse_zero = !getenv("NGP_ADAM_DENSE_ZERO");
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, step_size, beta1, beta2, eps, bc2_sqrt, weight_decay, grad_scale, zero_grad);
+                       exp_avg_sq, n, step_size, beta1, beta2, eps, bc2_sqrt, weight_decay, grad_scale, zero_grad,
+                       sparse_zero);
     return ngp_check_launch();
 }
 
