@@ -526,27 +526,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) g
     gemm_body<MODE, WM, WN, TM, TN, XF>(p);
 }
 
-// ---------------------------------------------------------------- streaming 2-layer forward (H = 128)
-// The weight matrix of a 128-wide layer is 64-80 KB: it fits the LDS of a CU next to nothing else,
+// ---------------------------------------------------------------- streaming 2-layer forward (H = 32 TN)
+// The weight matrix of a 128-wide layer is 64-80 KB: it fits the LDS of a CU next to little else,
 // and then nothing but the sample rows has to move.  One 512-thread workgroup per CU keeps W1 as
-// [n][k] (k contiguous, row stride K+4 floats: the 8 lanes of a ds_read_b128 phase hit 32 distinct
-// banks), W2 and b1 in LDS for its whole life; each of its 8 waves streams 32-row tiles on its own:
+// [n][k] (k contiguous, row stride K+4 floats: a lane's 16-byte slot is (n (K/4+1) + const) mod 16 with
+// K/4+1 odd, a permutation over each 16-lane group of ds_read_b128 — conflict-free), W2 and the biases in
+// LDS for its whole life; each of its 8 waves streams 32-row tiles on its own:
 //   A operand  : lane (row li, half lh) loads float4 x[row][8q+4lh .. +3] straight from global memory
 //                into registers — the reduction index may be permuted freely as long as A and B agree,
 //                so the 4 floats feed 4 consecutive 32x32x2 MFMA steps; no LDS staging, no transposition;
-//   B operand  : lane (column li, half lh) reads float4 W1[n][8q+4lh .. +3] from LDS;
-//   16 float4 of the NEXT tile replace the current ones one by one as they are consumed (rolling
+//   B operand  : lane (column li, half lh) reads float4 W1[n][8q+4lh .. +3] from LDS, one K step ahead;
+//   the KQ float4 of the NEXT tile replace the current ones one by one as they are consumed (rolling
 //   prefetch: a full tile of MFMA time, ~7 us, covers the load latency);
-// so the K loop has no barrier and no LDS write at all.  Epilogue as in gemm_fwd2_kernel (bias,
-// activation, hidden store, second layer by per-lane partial products and a transposing butterfly),
-// without the cross-wave combine because a wave owns all 128 columns of its rows.
+// so the K loop has no barrier and no LDS write at all.  Epilogue: the accumulators start at b1, the
+// activated tile leaves through a per-wave [32][32] LDS transposition as 16-byte stores, the second
+// layer is per-lane partial products and a transposing butterfly over the 32 lanes (as in
+// gemm_fwd2_kernel, without the cross-wave combine: a wave owns all H columns of its rows).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // The row prefetch is written as inline assembly with hand-placed s_waitcnt: vmcnt counts loads AND
 // stores in issue order, and the compiler's own bookkeeping answers a load that is older than the
 // stores of the previous tile's epilogue with a full drain at every tile start.  The piece loaded at
 // step q of tile t is read at step q of tile t+1 with exactly KQ-1 loads and all epilogue stores
-// (>= 17 for a full tile) issued after it, so vmcnt(STREAM_VMCNT) — "all but the STREAM_VMCNT youngest
+// (4 TN hidden stores + the outputs for a full tile) issued after it, so vmcnt(STREAM_VMCNT) — "all but the STREAM_VMCNT youngest
 // are done" — is always enough and never waits for more than a few of the oldest stores.
 template <int OFF>
 __device__ __forceinline__ void stream_load(f32x4& dst, const float* ptr)
