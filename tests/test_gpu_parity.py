@@ -588,6 +588,53 @@ def test_sumsq_and_clip_coef(ngp, n):
             assert abs(float(out[1]) - want) <= 1e-5 * want
 
 
+def test_streaming_mlp_kernels_ragged_sizes_and_strides(ngp):
+    """Same kernels over a spread of batch sizes (one row, tile size +-1, fewer tiles than waves, a few tiles
+    per wave) with padded leading dimensions, against fp64; and a row's result must not depend on the
+    batch it sits in (bit-identical rows between a batch and a prefix of it)."""
+    from ngp_amd._lib import call
+    H = 128
+    gen = torch.Generator(device=DEV).manual_seed(811)
+    for n, n_in, n_out, act1 in ((1, 128, 1, 3), (31, 144, 3, 1), (33, 160, 2, 1), (2049, 128, 4, 3), (65537, 144, 3, 1),
+                                 (70001, 128, 1, 3)):
+        ldx, ldh, ldo = n_in + 16, H + 4, n_out + 1
+        xbuf = torch.randn(n, ldx, device=DEV, generator=gen)
+        x = xbuf[:, 16:]                                   # 64-byte offset, padded rows (the field's colour input looks like this)
+        W1 = torch.randn(H, n_in, device=DEV, generator=gen) * 0.1
+        W2 = torch.randn(n_out, H, device=DEV, generator=gen) * 0.1
+        b1 = torch.randn(H, device=DEV, generator=gen) * 0.1
+        hbuf = torch.full((n, ldh), float("nan"), device=DEV)
+        obuf = torch.full((n, ldo), float("nan"), device=DEV)
+        call("mlp2_fwd", x, ldx, W1, n_in, b1, act1, W2, H, None, 0, n, n_in, H, n_out, hbuf, ldh, obuf, ldo)
+        f1 = torch.relu if act1 == 1 else torch.nn.functional.softplus
+        h64 = f1(x.double() @ W1.double().T + b1.double())
+        assert float((hbuf[:, :H].double() - h64).abs().max()) < 2e-5, n
+        assert float((obuf[:, :n_out].double() - h64 @ W2.double().T).abs().max()) < 2e-5, n
+        assert torch.isnan(hbuf[:, H:]).all() and torch.isnan(obuf[:, n_out:]).all()          # padding untouched
+        if n > 40:                                          # a prefix of the batch gives the same bits for its rows
+            m = n // 2 + 3
+            h2 = torch.empty(m, ldh, device=DEV)
+            o2 = torch.empty(m, ldo, device=DEV)
+            call("mlp2_fwd", x[:m], ldx, W1, n_in, b1, act1, W2, H, None, 0, m, n_in, H, n_out, h2, ldh, o2, ldo)
+            assert torch.equal(h2[:, :H], hbuf[:m, :H]) and torch.equal(o2[:, :n_out], obuf[:m, :n_out])
+        hidden = hbuf[:, :H]
+        dz2 = torch.randn(n, n_out, device=DEV, generator=gen)
+        g64 = (hidden.double() > 0).double() if act1 == 1 else -torch.expm1(-hidden.double())
+        dz1 = (dz2.double() @ W2.double()) * g64
+        dxb = torch.full((n, 132), float("nan"), device=DEV)
+        W1c = W1[:, n_in - 128:]
+        call("mlp_bwd_input", dz2, n_out, W2, H, hidden, ldh, act1, W1c, n_in, n, 128, H, n_out, dxb, 132, 0)
+        ref = dz1 @ W1c.double()
+        assert float((dxb[:, :128].double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), n
+        assert torch.isnan(dxb[:, 128:]).all()
+        dW1 = torch.zeros(H, n_in, device=DEV); dW2 = torch.zeros(n_out, H, device=DEV)
+        db1 = torch.zeros(H, device=DEV); db2 = torch.zeros(n_out, device=DEV)
+        call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, ldh, act1, x, ldx, n, n_in, H, n_out, dW1, n_in, db1, dW2, H, db2)
+        for got, want in ((dW1, dz1.T @ x.double()), (dW2, dz2.double().T @ hidden.double()), (db1, dz1.sum(0)),
+                          (db2, dz2.double().sum(0))):
+            assert float((got.double() - want).abs().max()) < 5e-6 * float(want.abs().max()) + 2e-6, (n, got.shape)
+
+
 @pytest.mark.parametrize("case", [
     # n_in, n_out, act1 (hidden), biases
     (128, 1, 3, True),      # xyz_net
