@@ -18,8 +18,8 @@ STATS=$(ls /tmp/p_stats/*/*_kernel_stats.csv | head -1)
 TRACE=$(ls /tmp/p_stats/*/*_kernel_trace.csv | head -1)
 python3 tools/prof_summary.py "$STATS" > gpurun_out/prof/r01_bench_kernel_stats.txt
 echo >> gpurun_out/prof/r01_bench_kernel_stats.txt
-python3 tools/timeline.py "$TRACE" region 40 >> gpurun_out/prof/r01_bench_kernel_stats.txt
-python3 tools/timeline.py "$TRACE" 3 > gpurun_out/prof/r01_timeline.txt
+python3 tools/timeline.py "$TRACE" region 40 8 >> gpurun_out/prof/r01_bench_kernel_stats.txt
+python3 tools/timeline.py "$TRACE" 12 > gpurun_out/prof/r01_timeline.txt
 python3 tools/timeline.py "$TRACE" update > gpurun_out/prof/r01_timeline_grid_update_step.txt
 if [ "$1" != "nopmc" ]; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 4 > gpurun_out/prof/pmc_fetch.log 2>&1

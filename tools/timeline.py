@@ -4,7 +4,8 @@ the run (steps are delimited by clip_coef_kernel launches, one per optimizer ste
 duration, queue and the idle gap on the device before it.  Also prints the busy/idle split of the step.
 
 usage: timeline.py <kernel_trace.csv> [steps_from_end=3]
-       timeline.py <kernel_trace.csv> region <K>     per-kernel time over the last K steps (bench.py's timed region)
+       timeline.py <kernel_trace.csv> region <K> [skip]   per-kernel time over K steps ending `skip` steps before the end
+                                                          (bench.py: 40 timed steps, then 8 untimed ones with all kernels bracketed)
        timeline.py <kernel_trace.csv> update         the last step that contains a density-grid update (packbits)
 """
 import csv
@@ -54,14 +55,14 @@ def main(path, back=3, with_update=False):
     print(f"# device idle inside the step: {idle/1e3:.1f} us of {wall/1e3:.1f} us")
 
 
-def region(path, k):
+def region(path, k, skip=0):
     rows = []
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if STEP_MARK in r[2]]
     # the timed region ends with the optimizer of its last step: take the K steps before the last mark
-    lo, hi = marks[-k - 1], marks[-1]
+    lo, hi = marks[-k - 1 - skip], marks[-1 - skip]
     sel = rows[lo:hi]
     wall = rows[hi][0] - rows[lo][0]
     agg = {}
@@ -70,7 +71,7 @@ def region(path, k):
         a[0] += e - s
         a[1] += 1
     tot = sum(a[0] for a in agg.values())
-    print(f"# timed region only (last {k} steps): wall {wall/k/1e6:.3f} ms/step, sum of kernel durations "
+    print(f"# timed region only ({k} steps, {skip} trailing steps skipped): wall {wall/k/1e6:.3f} ms/step, sum of kernel durations "
           f"{tot/k/1e6:.3f} ms/step (streams overlap), {len(sel)/k:.0f} launches/step")
     for name, (ns, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:24]:
         print(f"{name:60s} {ns/k/1e6:8.3f} ms/step {c/k:6.1f} calls/step {ns/c/1e3:9.1f} us/call")
@@ -78,7 +79,7 @@ def region(path, k):
 
 if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[2] == "region":
-        region(sys.argv[1], int(sys.argv[3]))
+        region(sys.argv[1], int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     elif len(sys.argv) > 2 and sys.argv[2] == "update":
         main(sys.argv[1], with_update=True)
     else:
