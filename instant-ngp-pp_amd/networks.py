@@ -78,6 +78,7 @@ _OVERLAP = _os.environ.get("NGP_NO_OVERLAP", "0") != "1"
 _FUSED_FWD = _os.environ.get("NGP_NO_FUSED_FWD", "0") != "1"   # A/B switch for ngp_mlp2_fwd
 _FUSED_BWD = _os.environ.get("NGP_NO_FUSED_BWD", "0") != "1"   # A/B switch for the operand-transform products
 # the library's streaming weight-gradient kernel (mlp_stream_wgrad_kernel) is on unless one of its A/B switches is set
+_SORT_GRID_SAMPLES = _os.environ.get("NGP_NO_SORT_GRID_SAMPLES", "0") != "1"   # A/B: Morton-sorted occupancy-update points
 _STREAM_WGRAD = not (_os.environ.get("NGP_MLP_NO_STREAM") or _os.environ.get("NGP_MLP_NO_STREAM_WGRAD"))
 # widest second layer that takes the fused route (tools/mlp_bwd_microbench.py, n = 433 k, MI355X):
 # density head 0.54 -> 0.49 ms, rgb_net 0.60 -> 0.57 ms, 32-wide headers 0.22 -> 0.22 ms
@@ -632,7 +633,14 @@ class NGP(nn.Module):
             pos = torch.searchsorted(csum, rank.clamp(min=1), right=False)
             indices2 = torch.where(n_occ > 0, pos.clamp(max=occ.numel() - 1), indices1)
             coords2 = vren.morton3D_invert(indices2.int())
-            cells += [(torch.cat([indices1, indices2]), torch.cat([coords1, coords2]))]
+            indices, coords = torch.cat([indices1, indices2]), torch.cat([coords1, coords2])
+            if _SORT_GRID_SAMPLES:
+                # Morton order: neighbouring points share hash-grid cells at the coarse levels, so the 1 M
+                # point gather of density() runs out of L2 instead of HBM (which cell receives which jitter
+                # draw changes, their distribution does not)
+                indices, perm = torch.sort(indices)
+                coords = coords[perm]
+            cells += [(indices, coords)]
         return cells
 
     @torch.no_grad()
