@@ -33,6 +33,9 @@ BYTES_PER_SAMPLE = {        # SURVEY.md §8(d), fp32, L=16, F=8 (per encoder, pe
     "grid_bwd_param": 4096 + 512,   # 4096 B of atomic adds + 512 B of dL_dy read
     "grid_bwd_input": 4096 + 512 + 12,
 }
+ADAM_BYTES_PER_PARAM = 28   # p, g, m, v read + p, m, v written (the gradient zero-fill is skipped
+                            # for pieces that are zero already, so it is not counted as algorithmic)
+ATOMIC_REQ_PEAK = 20.0e9    # memory-side 64-byte atomic requests/s (tools/atomic_shapes.hip, profiles/r02_atomic_shapes.txt)
 
 
 N_ARG = {"grid_fwd": 0, "grid_bwd_param": 1, "grid_bwd_input": 1}  # position of `n` among the int arguments
@@ -90,18 +93,36 @@ def cpu_baseline(model, scene, n_rays, n_samples):
              "psnr_hip_vs_cpu_path": _psnr(rgb_gpu, ref["rgb0"])}
     match["psnr_delta"] = match["psnr_hip_same_samples"] - match["psnr_cpu_path"]
     match["rays_compared"] = int(hit.sum())
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        nocuda.render([field, field], o, d, [n_samples])
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 50:
-            break
+    def timed(budget_s, max_reps):
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            nocuda.render([field, field], o, d, [n_samples])
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or reps >= max_reps:
+                return reps, el
+    all_threads = oracle.num_threads()
+    reps, el = timed(10.0, 50)
+    # the same sample on ONE thread as well (a scalar port's figure), a few seconds of it
+    oracle.set_num_threads(1)
+    reps1, el1 = timed(8.0, 3)
+    oracle.set_num_threads(all_threads)
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
-        "value": n_rays * reps / el, "unit": "rays/s", "cores": oracle.num_threads(), "kind": "port",
+        "value": n_rays * reps / el, "unit": "rays/s", "cores": all_threads, "kind": "port",
         "samples_per_s": n_rays * n_samples * reps / el,
         "sample": f"{reps}x forward render of {n_rays} rays x {n_samples} dense samples "
                   f"(oracle restatement of rendering_noCUDA.render + CPU hash-grid/MLP field, {el:.1f}s)",
+        "cpu_model": cpu_model,
+        "one_thread": {"value": n_rays * reps1 / el1, "unit": "rays/s", "cores": 1,
+                       "sample": f"{reps1}x the same render on 1 OpenMP thread ({el1:.1f}s)"},
         "parity": match,
     }
 
@@ -216,10 +237,13 @@ def main():
     # HIP events around EVERY kernel of the step cost 2.4 % of the step (measured A/B): inside the timed region
     # only the dominant kernel is bracketed (the roofline's live measurement); the other kernels' figures come
     # from a short untimed pass right after it
-    DOM = "grid_bwd_param"
-    prof_keys = ("grid_fwd", "grid_bwd_input", "adam_step", "linear_fwd", "linear_bwd_input",
-                 "linear_bwd_weight", "mlp_bwd_input", "mlp_bwd_weight", "mlp2_fwd")
-    _lib.PROFILE = {DOM: []}
+    # the two candidates for "dominant kernel" (the colour/density scatters and the clip+Adam sweep: 4 launches of
+    # ~60 per step) are both bracketed live; whichever took more device time per step in the timed region is the
+    # `roofline` kernel, the other one is reported beside it
+    LIVE = ("grid_bwd_param", "adam_step")
+    prof_keys = ("grid_fwd", "grid_bwd_input", "linear_fwd", "linear_bwd_input",
+                 "linear_bwd_weight", "mlp_bwd_input", "mlp_bwd_weight", "mlp2_fwd", "sumsq")
+    _lib.PROFILE = {k: [] for k in LIVE}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tot_samples, last = run(args.steps, args.warmup, False)
@@ -227,13 +251,35 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof_dom, _lib.PROFILE = _lib.PROFILE, {k: [] for k in prof_keys}
+    prof_live, _lib.PROFILE = _lib.PROFILE, {k: [] for k in prof_keys}
     post_steps = min(8, args.steps)
+    trainer.buckets.trace = []
     run(post_steps, args.warmup + args.steps, False)
     torch.cuda.synchronize()
+    comm_trace, trainer.buckets.trace = trainer.buckets.trace, None
+    # multi-GPU readiness: what every rank sent through the backend per step, and behind which HIP stream
+    main_stream = torch.cuda.current_stream().cuda_stream
+    per_step = {}
+    for ev in comm_trace:
+        key = (ev["op"], ev["bucket"], ev["stream"])
+        per_step[key] = per_step.get(key, 0) + ev["bytes"] / post_steps
+    comm = {"backend": (dist.get_backend() if dist.is_initialized() else None), "world_size": world,
+            "sharded_optimizer": bool(trainer.sharded),
+            "per_step": [{"op": op, "bucket": b, "MB": round(v / 1e6, 3),
+                          "enqueued_behind": "main stream" if st == main_stream else f"side stream {st:#x}"}
+                         for (op, b, st), v in sorted(per_step.items())]}
+    if world > 1 or solo_group:
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else "n/a"
+        except Exception:
+            rccl = "unknown"
+        print(f"[rank {rank}] {comm['backend']} world size {dist.get_world_size()} (RCCL {rccl}), "
+              f"sharded optimizer {trainer.sharded}; per step: " +
+              "; ".join(f"{c['op']} bucket {c['bucket']} {c['MB']} MB behind {c['enqueued_behind']}" for c in comm["per_step"]),
+              file=sys.stderr, flush=True)
     prof, _lib.PROFILE = _lib.PROFILE, None
-    prof[DOM] = prof_dom[DOM]
-    steps_of = lambda name: args.steps if name == DOM else post_steps
+    prof.update(prof_live)
+    steps_of = lambda name: args.steps if name in LIVE else post_steps
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     s = tot_samples.clone()
@@ -255,9 +301,12 @@ def main():
             if name.startswith("grid"):
                 # samples processed by each launch = the int64 `n` argument
                 ns = [a[N_ARG[name]] for _, _, a in evs]
-                gbs = [BYTES_PER_SAMPLE[name] * n / (m * 1e-3) / 1e9 for n, m in zip(ns, ms) if m > 0]
+                # achieved rate = sum of algorithmic bytes over sum of launch time (NOT the mean of per-launch
+                # ratios: the colour-table and density-table launches differ in duration)
                 kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
-                              "avg_samples": sum(ns) / len(ns), "GBps": sum(gbs) / max(len(gbs), 1)}
+                              "avg_samples": sum(ns) / len(ns),
+                              "algorithmic_bytes": float(BYTES_PER_SAMPLE[name]) * sum(ns),
+                              "GBps": BYTES_PER_SAMPLE[name] * sum(ns) / (sum(ms) * 1e-3) / 1e9}
             elif name.startswith("linear") or name.startswith("mlp"):
                 # (.., n, n_in, n_out, ..) are int arguments 2,3,4 of the three linear_* entry points and
                 # (n, n_in, H) arguments 5,6,7 of the fused 2-layer entry points (mlp2_fwd, mlp_bwd_*); only the MFMA-tiled
@@ -270,46 +319,75 @@ def main():
                     kern[name] = {"launches": len(sel), "total_ms": t_ms, "avg_ms": t_ms / len(sel),
                                   "TFLOPs": fl / (t_ms * 1e-3) / 1e12}
             elif name == "adam_step":
-                # 4 streams read + 4 written per parameter (p, g, m, v; the gradient is zeroed): 32 B each;
-                # the parameter count is the first int argument
-                tot_b = sum(32.0 * a[0] for _, _, a in evs)
+                # p, g, m, v read + p, m, v written per parameter = 28 B; the parameter count is
+                # the first int argument
+                tot_b = sum(float(ADAM_BYTES_PER_PARAM) * a[0] for _, _, a in evs)
                 kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
+                              "avg_params": sum(a[0] for _, _, a in evs) / len(evs), "algorithmic_bytes": tot_b,
                               "GBps": tot_b / (sum(ms) * 1e-3) / 1e9, "frac_of_hbm_peak": tot_b / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
             else:
                 kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms)}
         for name in kern:
             kern[name]["steps"] = steps_of(name)
+            kern[name]["ms_per_step"] = kern[name]["total_ms"] / kern[name]["steps"]
         grid_names = [k for k in kern if k.startswith("grid")]
-        heaviest = max(grid_names, key=lambda k: kern[k]["total_ms"] / kern[k]["steps"])
-        dom = DOM   # the kernel bracketed live in the timed region; `heaviest` is reported should another one out-weigh it
+        # dominant kernel = most device time per step among the live-bracketed candidates (timed region)
+        dom = max(LIVE, key=lambda k: kern[k]["ms_per_step"] if k in kern else 0.0)
+        heaviest = max(kern, key=lambda k: kern[k]["ms_per_step"])
         # HBM traffic per launch from the committed rocprofv3 --pmc passes over this same command
-        # (profiles/r01_pmc_traffic.json, tools/pmc_traffic.py): WRITE_SIZE is exact for fp32 atomics,
-        # FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B; calibrated here on the known
-        # 512 B/sample dL_dy stream, which it reports as 268 B).
-        traffic = None
-        try:
-            pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            pmc = pmc_all[dom]
-            traffic = (2 * pmc["fetch_bytes_per_sample"] + pmc["write_bytes_per_sample"]) * kern[dom]["avg_samples"]
-            # achieved HBM rate of every hash-grid kernel from the same PMC passes (FETCH_SIZE as reported, i.e.
-            # a lower bound for the gathers, + WRITE_SIZE) over the launch time measured in this run
-            for name in grid_names:
-                b = (pmc_all[name]["fetch_bytes_per_sample"] + pmc_all[name]["write_bytes_per_sample"]) * kern[name]["avg_samples"]
-                kern[name]["hbm_bytes_pmc"] = b
-                kern[name]["hbm_GBps_pmc"] = b / (kern[name]["avg_ms"] * 1e-3) / 1e9
-        except Exception:
-            pass
-        roofline = {
-            "kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-            "avg_launch_ms": kern[dom]["avg_ms"], "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE[dom],
-            "heaviest_grid_kernel_per_step": heaviest,
-            "note": "achieved = algorithmic bytes (4096 B of fp32 atomic adds + 512 B read per sample) / launch time; "
-                    "the kernel is bound by the memory-side atomic request rate (~22 G requests/s measured, "
-                    "~1.3 TB/s of added bytes in ideal shapes per MI355X_MICROARCH.md), not by the 8 TB/s used for "
-                    "frac; run merging with corner carry-over + zero skipping + x-pair coalescing cut the real traffic to `traffic` bytes"
-                    if dom == "grid_bwd_param" else "",
-        }
+        # (profiles/r02_pmc_traffic.json, tools/pmc_traffic.py): WRITE_SIZE is exact for fp32 atomics and 16-B
+        # streaming stores; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B).
+        pmc_all = {}
+        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pmc_all = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                pmc_all["_file"] = fn
+                break
+            except Exception:
+                continue
+
+        def traffic_of(name):
+            pmc = pmc_all.get(name)
+            if not pmc:
+                return None
+            if "fetch_bytes_per_sample" in pmc:
+                return (2 * pmc["fetch_bytes_per_sample"] + pmc["write_bytes_per_sample"]) * kern[name]["avg_samples"]
+            if "fetch_bytes_per_param" in pmc:
+                return (2 * pmc["fetch_bytes_per_param"] + pmc["write_bytes_per_param"]) * kern[name]["avg_params"]
+            return None
+
+        for name in grid_names:
+            pmc = pmc_all.get(name)
+            if pmc and "fetch_bytes_per_sample" in pmc:
+                b_ = (pmc["fetch_bytes_per_sample"] + pmc["write_bytes_per_sample"]) * kern[name]["avg_samples"]
+                kern[name]["hbm_bytes_pmc"] = b_
+                kern[name]["hbm_GBps_pmc"] = b_ / (kern[name]["avg_ms"] * 1e-3) / 1e9
+
+        def roof(name):
+            k = kern[name]
+            r = {"kernel": name, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": k["GBps"] / HBM_PEAK_GBS, "traffic": traffic_of(name), "traffic_source": pmc_all.get("_file"),
+                 "avg_launch_ms": k["avg_ms"], "ms_per_step": k["ms_per_step"], "launches": k["launches"],
+                 "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
+                 "formula": "achieved = sum over the timed region's launches of algorithmic bytes / sum of their HIP-event durations"}
+            if name == "grid_bwd_param":
+                r["algorithmic_bytes_per_sample"] = BYTES_PER_SAMPLE[name]
+                req = pmc_all.get(name, {}).get("atomic_requests_per_sample")
+                if req:
+                    rate = req * k["avg_samples"] / (k["avg_ms"] * 1e-3)
+                    r["atomic_requests"] = {"per_sample": req, "per_launch": req * k["avg_samples"], "rate_per_s": rate,
+                                            "peak_per_s": ATOMIC_REQ_PEAK, "frac": rate / ATOMIC_REQ_PEAK}
+                r["note"] = ("4096 B of fp32 atomic adds + 512 B read per sample; the binding resource is the memory-side "
+                             "atomic REQUEST rate (one request per 64-byte line a wave-instruction touches, 20 G/s "
+                             "measured: profiles/r02_atomic_shapes.txt), see `atomic_requests`; line-aligned run merging + "
+                             "zero skipping cut the real traffic to `traffic` bytes per launch")
+            else:
+                r["algorithmic_bytes_per_param"] = ADAM_BYTES_PER_PARAM
+                r["note"] = "clip + Adam sweep over all 200 M parameters: p, g, m, v read, p, m, v written"
+            return r
+        roofline = roof(dom)
+        roofline["heaviest_kernel_per_step"] = heaviest
+        roofline["other_candidate"] = roof([k for k in LIVE if k != dom and k in kern][0]) if len([k for k in LIVE if k in kern]) > 1 else None
         # MFMA utilisation of the MLP products against the dense f32 MFMA peak of gfx950
         lin = [kern[k] for k in kern if k.startswith("linear") or k.startswith("mlp")]
         mlp = None
@@ -335,9 +413,13 @@ def main():
                        "rays_per_gpu": args.rays, "global_rays": args.rays * world,
                        "occupancy": "analytic init" if args.analytic_init else "reference schedule from step 0",
                        "pretrain_steps": args.pretrain,
+                       "pipelining": "steady state: batch i+1 is marched on a side stream under step i, so the timed "
+                                     f"region marches {args.steps - 1} of its {args.steps} batches (the first was marched "
+                                     "under the last warm-up step) and runs every other stage of all of them",
                        "parallelism": f"ray-batch dp{world}"},
             "roofline": roofline,
             "mlp_mfma": mlp,
+            "comm": comm,
             "kernels": kern,
         }
         if world == 1 and not args.no_cpu_baseline:

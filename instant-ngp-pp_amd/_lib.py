@@ -58,14 +58,25 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        from . import build as _build  # builds with hipcc; raises if hipcc is absent
+    # The prototypes above come from the header as it is NOW; a library built from other sources would be
+    # called with the wrong argument lists.  build.py stamps the library with the digest of its sources:
+    # a missing or stale library is rebuilt when hipcc is present, and refused otherwise.
+    from . import build as _build
+    want = _build.source_id()
+    if not os.path.exists(LIB_PATH) or _build.built_id() != want:
+        if not _build.have_hipcc():
+            raise RuntimeError(f"{LIB_PATH} is missing or was built from other sources (id {_build.built_id()}, "
+                               f"sources {want}) and hipcc is not available to rebuild it")
         _build.build()
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argl) in PROTOS.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = restype
         fn.argtypes = [t for t, _ in argl]
+    got = lib.ngp_build_id().decode()
+    if got != want:
+        raise RuntimeError(f"{LIB_PATH} reports build id {got}, its sources have {want}: rebuild it "
+                           "(python -m instant-ngp-pp_amd.build)")
     _lib = lib
     return lib
 

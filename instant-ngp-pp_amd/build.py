@@ -1,5 +1,13 @@
 """Builds libngp_hip.so (gfx950) in-tree with hipcc.  No JIT cache: the .so sits next to the
-sources so that it travels with the repository snapshot to the GPU box."""
+sources so that it travels with the repository snapshot to the GPU box.
+
+Staleness is decided by CONTENT, not by mtime (a snapshot copy does not keep mtimes in order): every
+object remembers the digest of (source + headers + flags) it was compiled from, and the library carries the
+digest of all of them (`ngp_build_id()`, also written to libngp_hip.so.id) which `_lib.load()` checks against
+the sources it finds — a stale library is rebuilt when hipcc is there and refused when it is not.
+
+NGP_AB_VARIANTS=1 in the environment compiles the superseded kernel variants in as well (tools/*microbench*)."""
+import hashlib
 import os
 import shutil
 import subprocess
@@ -7,6 +15,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libngp_hip.so")
+LIB_ID = LIB + ".id"
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "ngp_hip.h")]
 
 # (source, extra flags).  ray_kernels.hip is compiled without FMA contraction so that the
 # marcher / intersector are bit-identical to the CPU oracle (see the file header).
@@ -19,6 +29,10 @@ SOURCES = [
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
+def _flags():
+    return COMMON + (["-DNGP_AB_VARIANTS"] if os.environ.get("NGP_AB_VARIANTS") else [])
+
+
 def _hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -26,33 +40,64 @@ def _hipcc():
     return exe
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def have_hipcc():
+    return bool(shutil.which("hipcc")) or os.path.exists("/opt/rocm/bin/hipcc")
+
+
+def _digest(paths, extra=()):
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    for e in extra:
+        h.update(e.encode())
+    return h.hexdigest()[:16]
+
+
+def source_id():
+    """digest of everything the library is built from (what ngp_build_id() of an up-to-date library returns)"""
+    srcs = [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, "build_id.cpp")]
+    extra = _flags() + [f for _, fl in SOURCES for f in fl]
+    return _digest(srcs + HEADERS, extra)
+
+
+def built_id():
+    try:
+        return open(LIB_ID).read().strip()
+    except OSError:
+        return None
 
 
 def build(force=False, verbose=False):
+    want = source_id()
+    if not force and os.path.exists(LIB) and built_id() == want:
+        return LIB
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "ngp_hip.h")]
     objs = []
-    for src, extra in SOURCES:
+    units = [(s, fl, []) for s, fl in SOURCES] + [("build_id.cpp", [], [f'-DNGP_BUILD_ID="{want}"'])]
+    for src, extra, defs in units:
         s = os.path.join(CSRC, src)
-        o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + extra + ["-c", s, "-o", o]
+        o = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        d = _digest([s] + HEADERS, _flags() + extra + defs)
+        stamp = o + ".sha"
+        have = open(stamp).read().strip() if os.path.exists(stamp) and os.path.exists(o) else None
+        if force or have != d:
+            cmd = [hipcc] + _flags() + extra + defs + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+            with open(stamp, "w") as f:
+                f.write(d)
         objs.append(o)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    with open(LIB_ID, "w") as f:
+        f.write(want)
     return LIB
 
 

@@ -21,7 +21,9 @@ def extract_model_state_dict(ckpt_path, model_name='model', prefixes_to_ignore=(
 
 def load_ckpt(model, ckpt_path, model_name='model', prefixes_to_ignore=()):
     """in-place update of `model` from a (slim) checkpoint; parameter storage (e.g. the trainer's
-    flat buffer views) is preserved because values are copied, not rebound"""
+    flat buffer views) is preserved because values are copied, not rebound.  Strict like the reference's
+    load_state_dict (utils.py:24-29): unknown keys and shape mismatches raise.  With a sharded-optimizer
+    trainer use NGPTrainer.load_ckpt (it refreshes the optimizer's master slices afterwards)."""
     if not ckpt_path:
         return
     state = extract_model_state_dict(ckpt_path, model_name, prefixes_to_ignore)
@@ -29,6 +31,9 @@ def load_ckpt(model, ckpt_path, model_name='model', prefixes_to_ignore=()):
     missing = [k for k in state if k not in own]
     if missing:
         raise KeyError(f"checkpoint keys not in the model: {missing[:5]}")
+    bad = [(k, tuple(v.shape), tuple(own[k].shape)) for k, v in state.items() if tuple(v.shape) != tuple(own[k].shape)]
+    if bad:
+        raise RuntimeError("size mismatch for " + ", ".join(f"{k}: checkpoint {a} vs model {b}" for k, a, b in bad[:5]))
     with torch.no_grad():
         for k, v in state.items():
             own[k].copy_(v.to(own[k].device))

@@ -141,6 +141,9 @@ __global__ void __launch_bounds__(256) grid_fwd_kernel(GridMeta meta, const floa
 }
 
 // ------------------------------------------------------------------ param gradient (H2)
+// The three kernels below are superseded by grid_bwd_param_slide_kernel and are compiled only into the A/B build
+// (NGP_AB_VARIANTS=1 python -m instant-ngp-pp_amd.build; tools/grid_microbench.py times them against the product kernel).
+#ifdef NGP_AB_VARIANTS
 template <int F>
 __global__ void __launch_bounds__(256) grid_bwd_param_kernel(GridMeta meta, const float* __restrict__ x,
                                                              const float* __restrict__ dL_dy, int64_t lddy,
@@ -314,8 +317,10 @@ __global__ void __launch_bounds__(256) grid_bwd_param_merge2_kernel(GridMeta met
     if (have) flush();
 }
 
-// merge2 with corner-level carry-over.  The run-merging kernels above flush all corners whenever
-// the CELL changes; but a sample that moves to a neighbouring cell keeps half (face move), a
+#endif  // NGP_AB_VARIANTS
+
+// Run merging with corner-level carry-over.  A plain run-merging kernel (keep the 8 corner sums in registers while
+// the sample stays in its cell) flushes all corners whenever the CELL changes; but a sample that moves to a neighbouring cell keeps half (face move), a
 // quarter (edge move) or one (diagonal move) of its eight corners.  Here every lane keeps its four
 // (y,z) accumulators addressed relative to a sliding 2x2x2 window: on a move of at most one cell
 // per axis only the corners that LEAVE the window are flushed, the others slide to their new slot
@@ -415,6 +420,140 @@ __global__ void __launch_bounds__(256) grid_bwd_param_slide_kernel(GridMeta meta
         put(a0, X, b1, b2); put(a1, X, b1 + 1, b2); put(a2, X, b1, b2 + 1); put(a3, X, b1 + 1, b2 + 1);
     }
 }
+
+// Line-aligned sliding window (F = 8: a table row is 32 bytes, a 64-byte atomic request covers the two
+// rows (2k, 2k+1) of a level).  Memory-side float atomics are limited by REQUESTS, one per 64-byte line a
+// wave-instruction touches (tools/atomic_shapes.hip: 20 G requests/s whether a request carries 4 or 64
+// bytes), so the unit of accumulation here is the LINE, not the row: per (y,z) corner slot a lane pair
+// keeps the sums of line A (the line holding row x0) and line B (the next line, used when x0 is the odd
+// row of its pair) and a line is flushed ONCE, whole, when the sample's 2x2x2 window has left it —
+// an x-step inside a line flushes nothing, where the row-window kernel above sends out a lone 32-byte
+// row.  Which x start a line (even or odd) is a property of the (y,z) row: even for hashed levels
+// (x enters the hash by xor, so x ^ 1 is the neighbour), parity of res * (y + z) for dense levels.
+// No cross-lane traffic: lane = (level, row-in-line, feature) owns its sums from first add to flush.
+// tools/scatter_model.py: 26.0 -> 22.7 requests per sample on a captured training batch.
+template <int CHUNK>
+__global__ void __launch_bounds__(256) grid_bwd_param_line_kernel(GridMeta meta, const float* __restrict__ x,
+                                                                  const float* __restrict__ dL_dy, int64_t lddy,
+                                                                  int64_t n, float* __restrict__ dtable)
+{
+    constexpr int F = 8;
+    constexpr int LV = 4;             // levels per wave: 16 lanes each
+    constexpr int SUB = 8;
+    const uint32_t L = meta.n_levels;
+    const uint32_t waves_per_chunk = (L + LV - 1) / LV;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t chunk = __builtin_amdgcn_readfirstlane((int)(wave_global / waves_per_chunk));
+    const uint32_t lg = __builtin_amdgcn_readfirstlane((int)(wave_global % waves_per_chunk));
+    const int lane = threadIdx.x & 63;
+    const uint32_t level = lg * LV + lane / (2 * F);
+    const int xb = (lane / F) & 1;    // this lane's row inside a line
+    const int f = lane % F;
+    const int64_t s0 = chunk * CHUNK;
+    if (s0 >= n) return;
+    const int64_t s1 = s0 + CHUNK < n ? s0 + CHUNK : n;
+    const bool active = level < L;
+    const LevelInfo li = level_info(meta, active ? level : 0);
+    const size_t ld = (size_t)lddy;
+    // dense level of odd resolution: the line pairing alternates with y + z
+    const int odd = (!(li.flags & 1u) && (li.res & 1u)) ? 1 : 0;
+
+    // slots (cy,cz) = (0,0) (1,0) (0,1) (1,1); A = line holding x = base, B = the line after it
+    float A0 = 0.0f, A1 = 0.0f, A2 = 0.0f, A3 = 0.0f, B0 = 0.0f, B1 = 0.0f, B2 = 0.0f, B3 = 0.0f;
+    int b0 = 0, b1 = 0, b2 = 0;
+    bool have = false;
+
+    // (macros, not lambdas taking references: the sums must stay in registers)
+#define NGP_PUT(a_, gx_, gy_, gz_)                                                                      \
+    do {                                                                                                \
+        if ((a_) != 0.0f) {                                                                             \
+            const uint32_t row_ = row_index(li, (uint32_t)(gx_), (uint32_t)(gy_), (uint32_t)(gz_));     \
+            atomicAdd(dtable + (size_t)row_ * F + f, (a_));                                             \
+        }                                                                                               \
+        (a_) = 0.0f;                                                                                    \
+    } while (0)
+    // first x of the line that holds x0 in the (y,z) row: x0 - ((x0 - parity) & 1)
+#define NGP_LINE_X(x0_, y_, z_) ((x0_) - (((x0_) - (odd & ((y_) + (z_)))) & 1))
+#define NGP_FLUSH_SLOT(a_, b_, x0_, y_, z_)                        \
+    do {                                                           \
+        const int xa_ = NGP_LINE_X(x0_, y_, z_) + xb;              \
+        NGP_PUT(a_, xa_, y_, z_); NGP_PUT(b_, xa_ + 2, y_, z_);    \
+    } while (0)
+    // the window's x base moved from xo to xn (|xn - xo| <= 1) in the (y,z) row of one slot
+#define NGP_STEP_X(a_, b_, xo_, xn_, y_, z_)                                             \
+    do {                                                                                 \
+        const int lo_ = NGP_LINE_X(xo_, y_, z_), ln_ = NGP_LINE_X(xn_, y_, z_);          \
+        if (ln_ > lo_) { NGP_PUT(a_, lo_ + xb, y_, z_); (a_) = (b_); (b_) = 0.0f; }      \
+        else if (ln_ < lo_) { NGP_PUT(b_, lo_ + 2 + xb, y_, z_); (b_) = (a_); (a_) = 0.0f; } \
+    } while (0)
+
+    for (int64_t sb = s0; sb < s1; sb += SUB) {
+        float g[SUB], px[SUB], py[SUB], pz[SUB];
+#pragma unroll
+        for (int j = 0; j < SUB; j++) {
+            const int64_t s = sb + j < s1 ? sb + j : s1 - 1;
+            g[j] = active ? dL_dy[(size_t)s * ld + level * F + f] : 0.0f;
+            px[j] = x[3 * s]; py[j] = x[3 * s + 1]; pz[j] = x[3 * s + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < SUB; j++) {
+            if (sb + j >= s1) break;
+            const float p0 = fmaf(li.scale, px[j], 0.5f), p1 = fmaf(li.scale, py[j], 0.5f), p2 = fmaf(li.scale, pz[j], 0.5f);
+            const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+            const int g0 = (int)f0, g1 = (int)f1, g2 = (int)f2;
+            const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+            const int dx = g0 - b0, dy = g1 - b1, dz = g2 - b2;
+            if (have && (dx | dy | dz) != 0) {
+                const bool near_move = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+                if (!near_move) {
+                    NGP_FLUSH_SLOT(A0, B0, b0, b1, b2); NGP_FLUSH_SLOT(A1, B1, b0, b1 + 1, b2);
+                    NGP_FLUSH_SLOT(A2, B2, b0, b1, b2 + 1); NGP_FLUSH_SLOT(A3, B3, b0, b1 + 1, b2 + 1);
+                } else {
+                    // (y,z) rows leaving the window go out whole; the others slide to their new slot
+                    const bool fy0 = dy == 1, fy1 = dy == -1, fz0 = dz == 1, fz1 = dz == -1;
+                    if (fy0 || fz0) NGP_FLUSH_SLOT(A0, B0, b0, b1, b2);
+                    if (fy1 || fz0) NGP_FLUSH_SLOT(A1, B1, b0, b1 + 1, b2);
+                    if (fy0 || fz1) NGP_FLUSH_SLOT(A2, B2, b0, b1, b2 + 1);
+                    if (fy1 || fz1) NGP_FLUSH_SLOT(A3, B3, b0, b1 + 1, b2 + 1);
+                    if (dy == 1) { A0 = A1; B0 = B1; A1 = 0.0f; B1 = 0.0f; A2 = A3; B2 = B3; A3 = 0.0f; B3 = 0.0f; }
+                    else if (dy == -1) { A1 = A0; B1 = B0; A0 = 0.0f; B0 = 0.0f; A3 = A2; B3 = B2; A2 = 0.0f; B2 = 0.0f; }
+                    if (dz == 1) { A0 = A2; B0 = B2; A2 = 0.0f; B2 = 0.0f; A1 = A3; B1 = B3; A3 = 0.0f; B3 = 0.0f; }
+                    else if (dz == -1) { A2 = A0; B2 = B0; A0 = 0.0f; B0 = 0.0f; A3 = A1; B3 = B1; A1 = 0.0f; B1 = 0.0f; }
+                    if (dx != 0) {
+                        NGP_STEP_X(A0, B0, b0, g0, g1, g2); NGP_STEP_X(A1, B1, b0, g0, g1 + 1, g2);
+                        NGP_STEP_X(A2, B2, b0, g0, g1, g2 + 1); NGP_STEP_X(A3, B3, b0, g0, g1 + 1, g2 + 1);
+                    }
+                }
+            }
+            b0 = g0; b1 = g1; b2 = g2; have = true;
+            // row x0 is row q of its line (q = 0: both corners in line A; q = 1: x0 closes line A, x0+1 opens line B)
+            const float gv = g[j];
+            const float xw0 = (1 - w0) * gv, xw1 = w0 * gv;
+            const float y0 = 1 - w1, y1 = w1, z0 = 1 - w2, z1 = w2;
+#define NGP_LINE_ACC(A_, B_, Y_, Z_, WY_, WZ_)                                    \
+            {                                                                     \
+                const int q = (g0 - (odd & ((Y_) + (Z_)))) & 1;                   \
+                const float va = q ? (xb ? xw0 : 0.0f) : (xb ? xw1 : xw0);        \
+                const float vb = (q && !xb) ? xw1 : 0.0f;                         \
+                A_ = fmaf(va * (WY_), (WZ_), A_);                                 \
+                B_ = fmaf(vb * (WY_), (WZ_), B_);                                 \
+            }
+            NGP_LINE_ACC(A0, B0, g1, g2, y0, z0)
+            NGP_LINE_ACC(A1, B1, g1 + 1, g2, y1, z0)
+            NGP_LINE_ACC(A2, B2, g1, g2 + 1, y0, z1)
+            NGP_LINE_ACC(A3, B3, g1 + 1, g2 + 1, y1, z1)
+#undef NGP_LINE_ACC
+        }
+    }
+    if (have) {
+        NGP_FLUSH_SLOT(A0, B0, b0, b1, b2); NGP_FLUSH_SLOT(A1, B1, b0, b1 + 1, b2);
+        NGP_FLUSH_SLOT(A2, B2, b0, b1, b2 + 1); NGP_FLUSH_SLOT(A3, B3, b0, b1 + 1, b2 + 1);
+    }
+}
+#undef NGP_PUT
+#undef NGP_LINE_X
+#undef NGP_FLUSH_SLOT
+#undef NGP_STEP_X
 
 // ------------------------------------------------------------------ input gradient (H3)
 // GROUP = lanes that belong to one sample (L * LPI, a power of two <= 64): their partial
@@ -751,35 +890,55 @@ int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* d
     if (n > 0 && lddy < (int64_t)m.n_levels * m.n_features) return NGP_EINVAL;
     if (n == 0) return NGP_OK;
     if (!x || !dL_dy || !dtable) return NGP_EINVAL;
-    const int64_t n_items = n * m.n_levels;
     hipStream_t st = (hipStream_t)stream;
     GRID_DISPATCH_F(m.n_features, {
         constexpr int CHUNK = 32;
+        constexpr int LV2 = 64 / (2 * F) > 0 ? 64 / (2 * F) : 1;
+        const int64_t waves2 = ((n + CHUNK - 1) / CHUNK) * ((m.n_levels + LV2 - 1) / LV2);
+#ifdef NGP_AB_VARIANTS
+        // A/B build only: the superseded variants, selected once per process
+        static const int variant = getenv("NGP_GRID_BWD_SIMPLE") ? 1 : getenv("NGP_GRID_BWD_NOPAIR") ? 2
+                                   : getenv("NGP_GRID_BWD_NOSLIDE") ? 3 : getenv("NGP_GRID_BWD_NOLINE") ? 4 : 0;
+        static const int lds_pad = getenv("NGP_SCATTER_LDS") ? atoi(getenv("NGP_SCATTER_LDS")) : 0;
         constexpr int LV = 64 / F;
         const int64_t waves = ((n + CHUNK - 1) / CHUNK) * ((m.n_levels + LV - 1) / LV);
-        if (getenv("NGP_GRID_BWD_SIMPLE")) // one atomic per (sample, level, corner, feature): kept for A/B timing
+        if (variant == 1) {
+            const int64_t n_items = n * m.n_levels;
             hipLaunchKernelGGL(grid_bwd_param_kernel<F>, dim3(ngp_blocks(n_items * F, 256)), dim3(256), 0, st, m, x,
                                dL_dy, lddy, n_items, dtable);
-        else if (F == 8 && !getenv("NGP_GRID_BWD_NOPAIR") && !getenv("NGP_GRID_BWD_NOSLIDE")) {
-            constexpr int LV2 = 64 / (2 * F) > 0 ? 64 / (2 * F) : 1;
-            const int64_t waves2 = ((n + CHUNK - 1) / CHUNK) * ((m.n_levels + LV2 - 1) / LV2);
-            hipLaunchKernelGGL((grid_bwd_param_slide_kernel<F, CHUNK>), dim3(ngp_blocks(waves2 * 64, 256)), dim3(256),
-                               0, st, m, x, dL_dy, lddy, n, dtable);
-        } else if (F == 8 && !getenv("NGP_GRID_BWD_NOPAIR")) {
-            constexpr int LV2 = 64 / (2 * F) > 0 ? 64 / (2 * F) : 1;
-            const int64_t waves2 = ((n + CHUNK - 1) / CHUNK) * ((m.n_levels + LV2 - 1) / LV2);
-            // optional occupancy cap (unused dynamic LDS per block) so that a kernel on another
-            // stream can share the CUs with this atomic-bound one
-            const char* cap = getenv("NGP_SCATTER_LDS");
-            hipLaunchKernelGGL((grid_bwd_param_merge2_kernel<F, CHUNK>), dim3(ngp_blocks(waves2 * 64, 256)), dim3(256),
-                               cap ? atoi(cap) : 0, st, m, x, dL_dy, lddy, n, dtable);
-        } else {
-            // optional occupancy cap (unused dynamic LDS per block) so that a kernel on another
-            // stream can share the CUs with this atomic-bound one
-            static const int lds_pad = getenv("NGP_SCATTER_LDS") ? atoi(getenv("NGP_SCATTER_LDS")) : 0;
+            return ngp_check_launch();
+        }
+        if (variant == 2) {
             hipLaunchKernelGGL((grid_bwd_param_merge_kernel<F, CHUNK>), dim3(ngp_blocks(waves * 64, 256)), dim3(256),
                                lds_pad, st, m, x, dL_dy, lddy, n, dtable);
+            return ngp_check_launch();
         }
+        if (variant == 3) {
+            hipLaunchKernelGGL((grid_bwd_param_merge2_kernel<F, CHUNK>), dim3(ngp_blocks(waves2 * 64, 256)), dim3(256),
+                               lds_pad, st, m, x, dL_dy, lddy, n, dtable);
+            return ngp_check_launch();
+        }
+        static const int line_chunk = getenv("NGP_SCATTER_CHUNK") ? atoi(getenv("NGP_SCATTER_CHUNK")) : 32;
+        if (F == 8 && variant == 0 && line_chunk != 32) {
+            const int64_t w = ((n + line_chunk - 1) / line_chunk) * ((m.n_levels + 3) / 4);
+            if (line_chunk == 64)
+                hipLaunchKernelGGL(grid_bwd_param_line_kernel<64>, dim3(ngp_blocks(w * 64, 256)), dim3(256), 0, st, m, x,
+                                   dL_dy, lddy, n, dtable);
+            else
+                hipLaunchKernelGGL(grid_bwd_param_line_kernel<128>, dim3(ngp_blocks(w * 64, 256)), dim3(256), 0, st, m, x,
+                                   dL_dy, lddy, n, dtable);
+            return ngp_check_launch();
+        }
+        const bool line = F == 8 && variant == 0;
+#else
+        const bool line = F == 8;
+#endif
+        if (line)    // F = 8 (the reference's tables): accumulate per 64-byte line
+            hipLaunchKernelGGL(grid_bwd_param_line_kernel<CHUNK>, dim3(ngp_blocks(waves2 * 64, 256)), dim3(256), 0, st,
+                               m, x, dL_dy, lddy, n, dtable);
+        else
+            hipLaunchKernelGGL((grid_bwd_param_slide_kernel<F, CHUNK>), dim3(ngp_blocks(waves2 * 64, 256)), dim3(256),
+                               0, st, m, x, dL_dy, lddy, n, dtable);
     });
     return ngp_check_launch();
 }

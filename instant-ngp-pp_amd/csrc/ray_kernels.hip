@@ -216,6 +216,7 @@ __device__ __forceinline__ MarchRay load_ray(const float* __restrict__ rays_o, c
     return c;
 }
 
+#ifdef NGP_AB_VARIANTS   // A/B build only (NGP_MARCH_LANE_PER_RAY=1): the serial lane-per-ray walk the wave kernel replaced
 // Pass 1: one lane per ray walks the occupancy bitfield ONCE, parks each accepted sample's t
 // in t_scratch[r*max_samples + k] (a lane's consecutive stores fall in the same L2 lines and
 // are merged there) and records the count.  The reference walks every ray twice.
@@ -248,6 +249,7 @@ __global__ void march_count_kernel(const float* __restrict__ rays_o, const float
     }
     counts[r] = n;
 }
+#endif  // NGP_AB_VARIANTS
 
 // Pass 1, wavefront-packed: one WAVE per ray.  Whatever the occupancy says, the marcher only ever
 // stands on elements of one chain t_{k+1} = t_k + dt(t_k) (an accepted sample advances by dt, a skip
@@ -257,8 +259,8 @@ __global__ void march_count_kernel(const float* __restrict__ rays_o, const float
 // elements at once — position, mip level, Morton bit test, and for an empty cell the index of the first
 // chain element behind it (binary search in the segment) — and the serial walk over the window
 // collapses to a few v_readlane hops through those per-lane successors.  Visited-and-occupied lanes
-// are the samples; their t's are written compacted, in order.  Same results as march_count_kernel,
-// bit for bit; ~20x shorter because the bitfield latency is paid once per 64 elements, not per step.
+// are the samples; their t's are written compacted, in order.  Same results as the serial lane-per-ray walk
+// (march_count_kernel, A/B build), bit for bit; ~20x shorter because the bitfield latency is paid once per 64 elements, not per step.
 __global__ void __launch_bounds__(256) march_wave_kernel(const float* __restrict__ rays_o,
                                                          const float* __restrict__ rays_d,
                                                          const float* __restrict__ hits_t,
@@ -578,12 +580,15 @@ int ngp_raymarching_train(const float* rays_o, const float* rays_d, const float*
                        !rays_a || !xyzs || !dirs || !deltas || !ts)) return NGP_EINVAL;
     if (sample_capacity < (int64_t)n_rays * max_samples) return NGP_EINVAL; // worst case must fit
     hipStream_t st = (hipStream_t)stream;
+#ifdef NGP_AB_VARIANTS
     static const bool lane_per_ray = getenv("NGP_MARCH_LANE_PER_RAY") != nullptr;   // A/B: the serial walk
     if (n_rays > 0 && lane_per_ray)
         hipLaunchKernelGGL(march_count_kernel, dim3(ngp_blocks(n_rays, 64)), dim3(64), 0, st,
                            rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, noise,
                            grid_size, max_samples, n_rays, t_scratch, ray_counts);
-    else if (n_rays > 0)
+    else
+#endif
+    if (n_rays > 0)
         hipLaunchKernelGGL(march_wave_kernel, dim3(ngp_blocks(n_rays, 4)), dim3(256), 0, st,
                            rays_o, rays_d, hits_t, density_bitfield, cascades, scale, exp_step_factor, noise,
                            grid_size, max_samples, n_rays, t_scratch, ray_counts);

@@ -58,6 +58,19 @@ class RayMarcher(torch.autograd.Function):
         return dL_drays_o, dL_drays_d, None, None, None, None, None, None, None
 
 
+def mark_full_cover(rays_a):
+    """Tags a rays_a tensor whose segments tile every sample row [0, N) and name every ray once — what the
+    marcher produces.  VolumeRenderer then skips the zero-fill of its outputs (the kernels write every row);
+    for any other rays_a (a subset of rays, trimmed segments) it zero-fills like the reference's
+    torch::zeros (volumerendering.cu:137-143, 280-283)."""
+    rays_a._ngp_full_cover = True
+    return rays_a
+
+
+def _out_alloc(rays_a):
+    return torch.empty if getattr(rays_a, "_ngp_full_cover", False) else torch.zeros
+
+
 class VolumeRenderer(torch.autograd.Function):
     """Front-to-back compositing with a variable number of samples per ray (training only).
     -> vr_samples (scalar), opacity (N_rays), depth (N_rays), rgb (N_rays,3), normal_pred (N_rays,3),
@@ -67,13 +80,15 @@ class VolumeRenderer(torch.autograd.Function):
     def forward(ctx, sigmas, rgbs, normals_pred, sems, deltas, ts, rays_a, T_threshold, classes):
         nr, N = rays_a.shape[0], sigmas.shape[0]
         dev = sigmas.device
-        total = torch.empty(nr, dtype=torch.int64, device=dev)
-        opacity = torch.empty(nr, dtype=_f32, device=dev)
-        depth = torch.empty(nr, dtype=_f32, device=dev)
-        rgb = torch.empty(nr, 3, dtype=_f32, device=dev)
-        normal_pred = torch.empty(nr, 3, dtype=_f32, device=dev)
-        sem = torch.empty(nr, classes, dtype=_f32, device=dev)
-        ws = torch.empty(N, dtype=_f32, device=dev)  # every row is covered by the marcher's rays_a
+        new = _out_alloc(rays_a)   # empty when the marcher's rays_a guarantees that every row is written
+        total = new(nr, dtype=torch.int64, device=dev)
+        opacity = new(nr, dtype=_f32, device=dev)
+        depth = new(nr, dtype=_f32, device=dev)
+        rgb = new(nr, 3, dtype=_f32, device=dev)
+        normal_pred = new(nr, 3, dtype=_f32, device=dev)
+        sem = new(nr, classes, dtype=_f32, device=dev)
+        ws = new(N, dtype=_f32, device=dev)
+        ctx.full_cover = new is torch.empty
         call("composite_train_fw", sigmas, rgbs, normals_pred, sems, deltas, ts, rays_a, float(T_threshold),
              int(classes), nr, total, opacity, depth, rgb, normal_pred, sem, ws)
         ctx.save_for_backward(sigmas, rgbs, normals_pred, deltas, ts, rays_a, opacity, depth, rgb, normal_pred, ws)
@@ -95,10 +110,11 @@ class VolumeRenderer(torch.autograd.Function):
         # The reference back-propagates all-zero gradients through the normal / semantic heads when
         # the loss ignores those maps; here they are simply not produced (None) and the field's
         # backward skips the heads.
-        d_sig = torch.empty(N, dtype=_f32, device=dev)
-        d_rgbs = torch.empty(N, 3, dtype=_f32, device=dev)
-        d_nrm = torch.empty(N, 3, dtype=_f32, device=dev) if dL_dnormal_pred is not None else None
-        d_sems = torch.empty(N, classes, dtype=_f32, device=dev) if dL_dsem is not None else None
+        new = torch.empty if ctx.full_cover else torch.zeros   # rows no segment covers get zero gradients
+        d_sig = new(N, dtype=_f32, device=dev)
+        d_rgbs = new(N, 3, dtype=_f32, device=dev)
+        d_nrm = new(N, 3, dtype=_f32, device=dev) if dL_dnormal_pred is not None else None
+        d_sems = new(N, classes, dtype=_f32, device=dev) if dL_dsem is not None else None
         if N == 0:   # no sample in the batch (every ray missed the occupied cells): nothing to propagate
             return d_sig, d_rgbs, d_nrm, d_sems, None, None, None, None, None
         call("composite_train_bw", z(dL_dopacity, nr), z(dL_ddepth, nr), z(dL_drgb, nr, 3),

@@ -68,7 +68,11 @@ def nerf_loss_and_grads(rgb, opacity, ws, deltas, ts, rays_a, target_rgb, lambda
     d_rgb = torch.empty(nr, 3, dtype=torch.float32, device=dev)
     d_op = torch.empty(nr, dtype=torch.float32, device=dev)
     dist = d_ws = None
-    if lambda_distortion > 0:
+    if lambda_distortion > 0 and N == 0:
+        # no sample in the whole batch (e.g. an empty occupancy grid): the distortion term and its gradient vanish
+        dist = torch.zeros(nr, dtype=torch.float32, device=dev)
+        d_ws = torch.empty(0, dtype=torch.float32, device=dev)
+    elif lambda_distortion > 0:
         dist = torch.empty(nr, dtype=torch.float32, device=dev)
         wi = torch.empty(N, dtype=torch.float32, device=dev)
         wti = torch.empty(N, dtype=torch.float32, device=dev)
@@ -161,6 +165,10 @@ class NeRFLoss(nn.Module):
         if self.lambda_distortion > 0:
             d['distortion'] = self._distortion(results)
         if kwargs.get('normal_ref', False):
+            if torch.is_grad_enabled() and getattr(results['Ro'], '_ngp_normals_have_grad', True) is False:
+                raise RuntimeError("normal_ref=True, but normals_raw carries no gradient: the Ro term would silently "
+                                   "train nothing.  Set model.differentiable_normals = True before render() "
+                                   "(NGPTrainer(loss_kwargs={'normal_ref': True}) does), see networks.NGP.forward")
             d['normal_ref_rp'] = self.lambda_normal_ref_rp * results['Rp']
             d['normal_ref_ro'] = self.lambda_normal_ref_ro * results['Ro']
         if kwargs.get('normal_mono', False):

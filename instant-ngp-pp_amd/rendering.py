@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from . import vren
 from ._lib import call
-from .custom_functions import RayAABBIntersector, RayMarcher, RefLoss, VolumeRenderer
+from .custom_functions import RayAABBIntersector, RayMarcher, RefLoss, VolumeRenderer, mark_full_cover
 
 MAX_SAMPLES = 1024
 NEAR_DISTANCE = 0.01
@@ -304,6 +304,7 @@ def _render_rays_train(model, rays_o, rays_d, hits_t, **kwargs):
             rays_a, xyzs, dirs, results['deltas'], results['ts'], total_samples = RayMarcher.apply(
                 rays_o, rays_d, hits_t[:, 0], model.density_bitfield, model.cascades, model.scale, exp_step_factor,
                 model.grid_size, MAX_SAMPLES)
+    mark_full_cover(rays_a)   # the marcher's segments tile [0, N): the compositor may skip its zero-fills
     results['rays_a'] = rays_a
     results['total_samples'] = total_samples
 
@@ -334,6 +335,9 @@ def _render_rays_train(model, rays_o, rays_d, hits_t, **kwargs):
     results['Ro'], results['Rp'] = RefLoss.apply(
         sigmas.detach().contiguous(), normals_diff, normals_ori,
         results['deltas'], results['ts'], rays_a, T_threshold)
+    # NeRFLoss(normal_ref=True) needs Ro to reach the density field through normals_raw (reference:
+    # create_graph=True, networks.py:186-196); the default field returns detached analytic normals
+    results['Ro']._ngp_normals_have_grad = bool(normals_raw.requires_grad)
     return results
 
 

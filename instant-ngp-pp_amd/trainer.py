@@ -51,6 +51,14 @@ class GradBuckets:
         # solo=False: a ONE-rank process group still sends every collective of the N>1 path through
         # the backend (a rehearsal of the RCCL calls on a single-GPU box, see NGPTrainer.force_sharded)
         self.solo = solo
+        # set to a list to record every collective issued from now on: (op, bucket, payload bytes, HIP stream the
+        # call was enqueued behind) — bench.py --gpus N prints it per rank
+        self.trace = None
+
+    def _note(self, op, i, nbytes):
+        if self.trace is not None:
+            st = torch.cuda.current_stream().cuda_stream if self.flat.is_cuda else 0
+            self.trace.append({"op": op, "bucket": int(i), "bytes": int(nbytes), "stream": int(st)})
 
     @property
     def world(self):
@@ -72,6 +80,7 @@ class GradBuckets:
         if self.world == 1 and self.solo:
             return
         lo, hi = self.bounds[i], self.bounds[i + 1]
+        self._note("all_reduce", i, 4 * (hi - lo))
         self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def reduce_scatter_bucket(self, i, out):
@@ -79,6 +88,7 @@ class GradBuckets:
         if self.world == 1 and self.solo:
             return
         lo, hi = self.bounds[i], self.bounds[i + 1]
+        self._note("reduce_scatter", i, 4 * (hi - lo))
         if self._native_rs():
             self.works.append(dist.reduce_scatter_tensor(out, self.flat[lo:hi], op=dist.ReduceOp.SUM,
                                                          group=self.group, async_op=True))
@@ -93,6 +103,7 @@ class GradBuckets:
         if self.world == 1 and self.solo:
             return None
         lo, hi = self.bounds[i], self.bounds[i + 1]
+        self._note("all_gather", i, 4 * (hi - lo))
         if self._native_rs():
             w = dist.all_gather_into_tensor(flat_param[lo:hi], shard, group=self.group, async_op=True)
         else:
@@ -119,8 +130,12 @@ def shard_seed(base_seed, rank):
 class NGPTrainer:
     def __init__(self, model, lr=1e-2, num_epochs=20, steps_per_epoch=1000, clip_norm=50.0,
                  exp_step_factor=0.0, num_classes=7, density_threshold=0.01, render_kwargs=None, group=None,
-                 force_sharded=None):
-        """force_sharded: take the sharded-optimizer path (reduce-scatter / Adam on the slice / all-gather)
+                 force_sharded=None, loss_kwargs=None):
+        """loss_kwargs: the flags train.py:289-300 hands to NeRFLoss (normal_ref, normal_mono, semantic,
+        depth_mono, embed_msk, scale, ...).  Any optional term switches the fused default-recipe loss off;
+        normal_ref also switches the field to differentiable normals (the Ro term must reach the density
+        table through normals_raw, reference networks.py:186-196).
+        force_sharded: take the sharded-optimizer path (reduce-scatter / Adam on the slice / all-gather)
         even with ONE rank in the process group, so that a single-GPU box can rehearse every RCCL call of
         the N>1 path; None reads the environment variable NGP_FORCE_SHARDED."""
         self.model = model
@@ -134,14 +149,21 @@ class NGPTrainer:
         self.density_threshold = density_threshold
         self.render_kwargs = dict(render_kwargs or {})
         self.loss_fn = NeRFLoss()
-        self.fused_loss = True   # default recipe (rgb + opacity + distortion); False -> NeRFLoss module
+        self.loss_kwargs = dict(loss_kwargs or {})
+        optional = any(self.loss_kwargs.get(k) for k in ("normal_ref", "normal_mono", "semantic", "depth_mono", "embed_msk"))
+        self.fused_loss = not optional   # default recipe (rgb + opacity + distortion); False -> NeRFLoss module
+        if self.loss_kwargs.get("normal_ref"):
+            model.differentiable_normals = True
         self.warmup_steps = 256
         self.update_interval = 16
         self.global_step = 0
         self.group = group
         self._grad_zeroed = None
         self._flatten()
-        self._opt_stream = torch.cuda.Stream(device=self.flat_param.device) if self.flat_param.is_cuda else None
+        # NGP_SERIAL_OPT=1 (A/B): clip + Adam on the caller's stream instead of the optimizer stream
+        serial = os.environ.get("NGP_SERIAL_OPT", "0") == "1"
+        self._opt_stream = (torch.cuda.current_stream(self.flat_param.device) if serial
+                            else torch.cuda.Stream(device=self.flat_param.device)) if self.flat_param.is_cuda else None
         self._march_ahead = MarchAhead(self.flat_param.device) if self.flat_param.is_cuda else None
 
     # ------------------------------------------------------------------ flat parameter store
@@ -232,8 +254,12 @@ class NGPTrainer:
     def lr(self):
         return self.lr_at(min(self.global_step // self.steps_per_epoch, self.num_epochs))
 
-    def step(self, rays_o, rays_d, rgb_gt, next_rays=None):
+    def step(self, rays_o, rays_d, rgb_gt, next_rays=None, target=None, **loss_kwargs):
         """one training step on this rank's ray batch; returns (loss tensor, results dict).
+
+        target: further per-ray supervision for NeRFLoss's optional terms ('normal', 'label', 'depth': the
+        batch dictionary of train.py:299); loss_kwargs: per-step additions to the trainer's loss_kwargs
+        (e.g. mask=..., step=...).
 
         next_rays = (rays_o, rays_d) of the FOLLOWING step, if the caller already has them (a
         data loader that is one batch ahead): their AABB test and occupancy march are then run on a
@@ -258,7 +284,7 @@ class NGPTrainer:
         results = render(model, rays_o, rays_d, exp_step_factor=self.exp_step_factor,
                          num_classes=self.num_classes, marched=marched, **self.render_kwargs)
         self._norm_share_armed, self._norm_share_fired = True, 0   # one backward follows, then the optimizer step
-        if self.fused_loss:
+        if self.fused_loss and not loss_kwargs and not target:
             # same value and gradients as sum(term.mean()) over NeRFLoss's default terms; the
             # gradients are seeded directly (no loss node, no multiplications by 1)
             terms, (d_rgb, d_op, d_ws) = nerf_loss_and_grads(
@@ -271,7 +297,11 @@ class NGPTrainer:
                 seeds.append(d_ws)
             torch.autograd.backward(outs, seeds)
         else:
-            loss_d = self.loss_fn(results, {"rgb": rgb_gt})
+            batch = {"rgb": rgb_gt}
+            batch.update(target or {})
+            kw = dict(self.loss_kwargs)
+            kw.update(loss_kwargs)
+            loss_d = self.loss_fn(results, batch, **kw)
             loss = sum(lo.mean() for lo in loss_d.values())
             loss.backward()
         self.optimizer_step()
@@ -363,6 +393,26 @@ class NGPTrainer:
             if ev is not None:
                 ev.wait()
 
+    # ------------------------------------------------------------------ parameter store <-> shards
+    def sync_shards(self):
+        """Sharded optimizer only: the rank's master parameter slices (what Adam updates and the all-gather
+        publishes) are re-read from the flat parameter buffer.  Call after ANY write into the model's
+        parameters from outside the optimizer (checkpoint load, manual initialisation): otherwise the next
+        all-gather overwrites those writes with the stale slices."""
+        self.wait()
+        if self.sharded:
+            with torch.no_grad():
+                for ps, (a, b) in zip(self.param_shard, self.shards):
+                    ps.copy_(self.flat_param[a:b])
+
+    def load_ckpt(self, ckpt_path, model_name='model', prefixes_to_ignore=()):
+        """utils.load_ckpt into the trainer's flat parameter store (values are copied into the existing
+        views, shapes are checked), followed by sync_shards()."""
+        from .ckpt import load_ckpt
+        self.wait()
+        load_ckpt(self.model, ckpt_path, model_name, prefixes_to_ignore)
+        self.sync_shards()
+
     # ------------------------------------------------------------------ multi-GPU helpers
     def broadcast_state(self, src=0):
         """start every rank from rank `src`'s parameters and occupancy grid (DDP does this at
@@ -370,9 +420,7 @@ class NGPTrainer:
         if self.buckets.world == 1 and self.buckets.solo:
             return
         dist.broadcast(self.flat_param, src, group=self.group)
-        if self.sharded:
-            for ps, (a, b) in zip(self.param_shard, self.shards):
-                ps.copy_(self.flat_param[a:b])
+        self.sync_shards()
         for name in ("density_grid", "density_bitfield"):
             if hasattr(self.model, name):
                 dist.broadcast(getattr(self.model, name), src, group=self.group)

@@ -131,12 +131,12 @@ def composite_train_fw(sigmas, rgbs, normals_pred, sems, deltas, ts, rays_a, T_t
     _chk(sigmas=sigmas, rgbs=rgbs, normals_pred=normals_pred, sems=sems, deltas=deltas, ts=ts, rays_a=rays_a)
     nr, N = rays_a.shape[0], sigmas.shape[0]
     dev = sigmas.device
-    total = torch.empty(nr, dtype=torch.int64, device=dev)
-    opacity = torch.empty(nr, dtype=_f32, device=dev)
-    depth = torch.empty(nr, dtype=_f32, device=dev)
-    rgb = torch.empty(nr, 3, dtype=_f32, device=dev)
-    normal = torch.empty(nr, 3, dtype=_f32, device=dev)
-    sem = torch.empty(nr, classes, dtype=_f32, device=dev)
+    total = torch.zeros(nr, dtype=torch.int64, device=dev)   # torch::zeros, volumerendering.cu:137-143
+    opacity = torch.zeros(nr, dtype=_f32, device=dev)
+    depth = torch.zeros(nr, dtype=_f32, device=dev)
+    rgb = torch.zeros(nr, 3, dtype=_f32, device=dev)
+    normal = torch.zeros(nr, 3, dtype=_f32, device=dev)
+    sem = torch.zeros(nr, classes, dtype=_f32, device=dev)
     ws = torch.zeros(N, dtype=_f32, device=dev)
     call("composite_train_fw", sigmas, rgbs, normals_pred, sems, deltas, ts, rays_a, float(T_threshold), int(classes),
          nr, total, opacity, depth, rgb, normal, sem, ws)

@@ -330,3 +330,8 @@ def linear_fwd(x, W, b, act):
 
 def num_threads():
     return int(lib().ngp_cpu_num_threads())
+
+
+def set_num_threads(n):
+    """OpenMP threads of the C restatement from now on (bench.py: the CPU baseline at 1 thread and at all of them)"""
+    lib().ngp_cpu_set_num_threads(int(n))

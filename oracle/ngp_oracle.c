@@ -784,6 +784,17 @@ int ngp_cpu_linear_fwd(const float* x, int64_t ldx, const float* W, const float*
     return 0;
 }
 
+/* bench.py times the CPU baseline at 1 thread and at all threads */
+void ngp_cpu_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int ngp_cpu_num_threads(void)
 {
 #ifdef _OPENMP

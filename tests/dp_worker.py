@@ -62,6 +62,84 @@ def run(trainer, data):
     return losses
 
 
+def check_bucket0_order(tr, model, batch, cdev):
+    """Bucket 0's reduce-scatter is fired from the colour encoder's backward, on the SIDE stream the colour
+    scatter was forked to (networks._FieldFn.backward): it must see the complete colour-table gradient.  One
+    backward with the hook (sharded path as trained), one with the hook off into a zeroed buffer; the rank's
+    slice of the summed hook-less gradients must equal what the hooked reduce-scatter delivered."""
+    from ngp_amd.losses import nerf_loss_and_grads
+    from ngp_amd.rendering import render
+    o, d, gt = batch
+    tr.wait()
+    world = dist.get_world_size()
+    b0 = tr.buckets.bounds[1]
+    a, b = tr.shards[0]
+
+    def backward_only():
+        res = render(model, o, d, exp_step_factor=0.0, num_classes=7)
+        terms, (d_rgb, d_op, d_ws) = nerf_loss_and_grads(res["rgb"], res["opacity"], res["ws"], res["deltas"], res["ts"],
+                                                        res["rays_a"], gt, 2e-4, 3e-4)
+        torch.autograd.backward([res["rgb"], res["opacity"], res["ws"]], [d_rgb, d_op, d_ws])
+
+    assert tr.hooked0
+    tr.flat_grad.zero_()
+    torch.cuda.synchronize()
+    backward_only()                       # fires reduce_scatter_bucket(0, grad_shard[0]) from the encoder hook
+    tr.buckets.wait()
+    torch.cuda.synchronize()
+    hooked = tr.grad_shard[0].clone()
+    hook, model.rgb_encoder.on_grad_ready = model.rgb_encoder.on_grad_ready, None
+    tr.flat_grad.zero_()
+    torch.cuda.synchronize()
+    backward_only()
+    torch.cuda.synchronize()
+    model.rgb_encoder.on_grad_ready = hook
+    full = tr.flat_grad[:b0].to(cdev).clone()
+    dist.all_reduce(full)
+    mine = full[a:b].to(hooked.device)
+    tr.flat_grad.zero_()
+    scale = float(mine.abs().max())
+    err = float((mine - hooked).abs().max())
+    nz = int((mine != 0).sum())
+    print(f"rank{dist.get_rank()}: bucket-0 reduce-scatter vs complete colour-table gradient: max |diff| {err:.3e} "
+          f"(max |g| {scale:.3e}, {nz} non-zero entries in the slice, world {world})", flush=True)
+    return nz > 1000 and err <= 2e-5 * scale
+
+
+def check_sharded_checkpoint(tr, model, batch, dev, rank, cdev):
+    """a checkpoint loaded into a sharded-optimizer trainer must be what the next step starts from
+    (NGPTrainer.load_ckpt -> sync_shards); a plain copy into the flat buffer would be overwritten by the stale
+    master slices at the first all-gather."""
+    import tempfile
+    from ngp_amd import ckpt
+    small = ("xyz_net.0.weight", "xyz_net.2.weight", "rgb_net.params")
+    path = os.path.join(tempfile.gettempdir(), f"ngp_dp_ckpt_{os.environ.get('MASTER_PORT', '0')}.ckpt")
+    if rank == 0:
+        src = build(dev)
+        with torch.no_grad():
+            src.density_bitfield.copy_(model.density_bitfield)   # a slim checkpoint carries the occupancy bitfield
+            for k, p in src.named_parameters():
+                if k in small:
+                    p.fill_(0.37)
+        ckpt.save_ckpt(src, path)
+        torch.save({"state_dict": ckpt.slim_ckpt(path)}, path)
+        del src
+    dist.barrier()
+    tr.load_ckpt(path)
+    o, d, gt = batch
+    tr.step(o, d, gt)
+    tr.wait()
+    torch.cuda.synchronize()
+    named = dict(model.named_parameters())
+    worst = max(float((named[k] - 0.37).abs().max()) for k in small)
+    print(f"rank{rank}: after load_ckpt + one sharded step the MLP weights are within {worst:.3e} of the checkpoint "
+          f"(lr 1e-2)", flush=True)
+    dist.barrier()
+    if rank == 0:
+        os.remove(path)
+    return worst <= 1.01e-2
+
+
 def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -92,6 +170,8 @@ def main():
     small = ("xyz_net.0.weight", "xyz_net.0.bias", "xyz_net.2.weight", "xyz_net.2.bias", "rgb_net.params")
     sharded_params = {k: v.detach().clone() for k, v in model.named_parameters() if k in small}
     ok = True
+    ok = check_bucket0_order(tr, model, mine[0], cdev) and ok
+    ok = check_sharded_checkpoint(tr, model, mine[0], dev, rank, cdev) and ok
     sub = dist.new_group([0])          # (collective) 1-rank subgroup for the unsharded comparison run on rank 0
     if rank == 0:
         del tr

@@ -550,8 +550,110 @@ def g9_density_grid_update():
     npz("g11_invisible_cells.npz", **vis)
 
 
+def g13_tonemapper():
+    """M4 (networks.py:150-163, 229-240): the reference's OWN NGP(rgb_act='None') — rgb_net without output
+    activation, log-radiance -> TruncExp with output_radiance=True, else the three per-channel tone-mapper
+    networks (1 -> 64 -> 1, sigmoid).  networks.py calls self.log_radiance_to_rgb without defining it
+    (SURVEY.md Appendix C); the method body exists in models/networks_noCUDA.py:238-259 and is bound onto
+    the class here, unchanged (that module imports the non-existent models/rendering_old for one
+    constant, which is stubbed).  Recorded: forward / forward_test with output_radiance, with the
+    tone-mappers at unit exposure, and with a per-sample `exposure`."""
+    sys.path.insert(0, OUT)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import tcnn_cpu_shim
+    sys.modules["tinycudann"] = tcnn_cpu_shim
+    stub = types.ModuleType("models.rendering_old")
+    stub.NEAR_DISTANCE = 0.01
+    sys.modules["models.rendering_old"] = stub
+    from models import networks as ref_net
+    from models import networks_noCUDA as ref_nocuda
+    ref_net.NGP.log_radiance_to_rgb = ref_nocuda.NGP.log_radiance_to_rgb
+    torch.manual_seed(SEED + 13)
+    g = np.random.default_rng(SEED + 14)
+    model = ref_net.NGP(scale=0.5, rgb_act='None')
+    cases = {}
+    with torch.no_grad():
+        model.xyz_encoder.params.copy_(torch.from_numpy(table_rule(model.xyz_encoder.params.numel())))
+        model.rgb_encoder.params.copy_(torch.from_numpy(table_rule(model.rgb_encoder.params.numel())))
+        for name, p in model.named_parameters():
+            if name.startswith("xyz_net") or name in ("rgb_net.params", "norm_pred_header.params",
+                                                      "semantic_header.params") or name.startswith("tonemapper_net"):
+                amp = 0.6 if name.startswith("tonemapper_net") else 0.15
+                p.copy_(torch.from_numpy((g.standard_normal(p.shape) * amp).astype(np.float32)))
+                cases[name] = p.detach().clone()
+    n = 160
+    x = ((g.random((n, 3)) - 0.5) * 0.95).astype(np.float32)
+    d = g.standard_normal((n, 3)).astype(np.float32)
+    exposure = (0.25 + 3.0 * g.random((n, 1))).astype(np.float32)
+    cases["x"], cases["d"], cases["exposure"] = x, d, exposure
+    X, D = torch.from_numpy(x), torch.from_numpy(d)
+    for tag, kw in (("radiance", {"output_radiance": True}), ("ldr", {}), ("ldr_exposure", {"exposure": torch.from_numpy(exposure)})):
+        outs = model(X.clone(), D, **kw)
+        cases[f"fwd_{tag}_rgbs"], cases[f"fwd_{tag}_sigmas"] = outs[1].detach(), outs[0].detach()
+        outs = model.forward_test(X.clone(), D, **kw)
+        cases[f"test_{tag}_rgbs"] = outs[1].detach()
+    # the unit-exposure regulariser of train.py:301-306 evaluates the tone-mappers at zero log-radiance
+    cases["unit_exposure_rgb"] = model.log_radiance_to_rgb(torch.zeros(1, 3), exposure=torch.ones(1, 1)).detach()
+    npz("g13_tonemapper.npz", **cases)
+
+
+def g14_loss_terms():
+    """The reference's OWN losses.py::NeRFLoss with every optional term switched on (losses.py:107-132:
+    normal_ref, normal_mono, semantic + sky_depth, depth_mono) on synthetic per-ray results / targets, and
+    compute_scale_and_shift; vren's distortion entry points = the C oracle.  Values and the gradients of
+    sum(term.mean()) (train.py:307) w.r.t. every differentiable result are recorded."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import oracle
+    install_oracle_vren(oracle)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_losses", REF + "/losses.py")
+    ref_losses = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_losses)
+    torch.manual_seed(SEED + 15)
+    nr, C = 200, 7
+    counts = torch.randint(0, 12, (nr,))
+    counts[::17] = 0
+    starts = torch.cumsum(counts, 0) - counts
+    rays_a = torch.stack([torch.arange(nr), starts, counts], 1).long()
+    N = int(counts.sum())
+    res = {
+        "rgb": torch.rand(nr, 3), "opacity": torch.rand(nr) * 0.98 + 0.01, "depth": torch.rand(nr) * 4,
+        "normal_pred": torch.randn(nr, 3), "semantic": torch.randn(nr, C),
+        "ws": torch.rand(N) * 0.2, "deltas": torch.rand(N) * 0.01 + 1e-3, "ts": torch.sort(torch.rand(N) * 3)[0],
+        "rays_a": rays_a, "Ro": torch.rand(nr), "Rp": torch.rand(nr, 3),
+    }
+    label = torch.randint(0, C, (nr,))
+    label[::9] = 4            # sky
+    label[5::23] = 256        # ignore_index
+    depth_gt = torch.rand(nr) * 60
+    depth_gt[::7] = 0         # invalid depth
+    tgt = {"rgb": torch.rand(nr, 3), "normal": torch.randn(nr, 3), "label": label, "depth": depth_gt}
+    diff = ("rgb", "opacity", "depth", "normal_pred", "semantic", "ws", "Ro", "Rp")
+    for k in diff:
+        res[k].requires_grad_(True)
+    kw = dict(normal_ref=True, normal_mono=True, semantic=True, depth_mono=True, scale=0.5)
+    loss_d = ref_losses.NeRFLoss()(res, tgt, **kw)
+    loss = sum(lo.mean() for lo in loss_d.values())
+    loss.backward()
+    cases = {"in_" + k: v.detach() for k, v in res.items()}
+    cases.update({"tgt_" + k: v for k, v in tgt.items()})
+    cases.update({"term_" + k: v.detach() for k, v in loss_d.items()})
+    cases["loss"] = loss.detach()
+    cases.update({"grad_" + k: res[k].grad for k in diff})
+    valid = depth_gt / 25 > 0
+    sc, sh = ref_losses.compute_scale_and_shift(res["depth"][valid].detach(), (depth_gt / 25)[valid])
+    cases["scale_shift"] = torch.stack([sc, sh])
+    cases["scene_scale"] = np.float64(kw["scale"])
+    npz("g14_loss_terms.npz", **cases)
+
+
 if __name__ == "__main__":
     cf, rn = import_reference()
+    only = set(sys.argv[1:])     # e.g. `make_golden.py g13 g14` regenerates just those fixtures
+    if only:
+        for name in sorted(only):
+            {"g13": g13_tonemapper, "g14": g14_loss_terms}[name]()
+        raise SystemExit(0)
     g1_raw2outputs(cf)
     g2_sample_pdf(cf)
     g3_render(cf, rn)
@@ -560,3 +662,5 @@ if __name__ == "__main__":
     g6_ngp_field()
     g7_render_paths()
     g9_density_grid_update()
+    g13_tonemapper()
+    g14_loss_terms()

@@ -1216,6 +1216,14 @@ def test_render_with_no_samples(ngp):
     assert int(test["total_samples"]) == 0 and not test["rgb"].any()
     ref = render(model, o, d, test_time=True, exp_step_factor=0.0, reference_test_loop=True)
     assert torch.equal(test["rgb"], ref["rgb"]) and torch.equal(test["opacity"], ref["opacity"])
+    # a whole trainer step on such a batch (fused loss kernels, clip + Adam): finite loss, no fault
+    from ngp_amd.trainer import NGPTrainer
+    tr = NGPTrainer(model, lr=1e-2)
+    tr.global_step = 1                    # no occupancy update: the grid stays empty
+    loss, res = tr.step(o, d, torch.rand(300, 3, device=DEV))
+    tr.wait()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and int(res["total_samples"]) == 0
 
 
 def test_render_matches_reference_render_golden(ngp, golden, monkeypatch):
@@ -1628,3 +1636,215 @@ def test_neg_normalize_and_refloss_inputs(ngp):
     nd, no = _RefLossInputs.apply(n_raw, n_pred, dirs)
     close(N(nd), N((n_raw - n_pred) ** 2), 1e-6, 1e-7)
     close(N(no), N(torch.clamp((n_raw * F_.normalize(dirs, dim=-1, eps=1e-6)).sum(-1), min=0.) ** 2), 1e-5, 1e-6)
+
+
+# ---------------------------------------------------------------------------- round 2: direct fixture checks
+def test_hip_composite_train_fw_matches_raw2outputs_golden(ngp, golden):
+    """SURVEY §8(c) cross-oracle identity, on the HIP kernel itself: vren.composite_train_fw with
+    deltas = dz*|d| (last 1e10) and T_threshold = 0 equals the reference's own raw2outputs (G1)."""
+    g = golden("g1_raw2outputs.npz")
+    checked = 0
+    for i in range(int(g["n_cases"])):
+        p = f"c{i}_"
+        raw, z, d = g[p + "raw"], g[p + "z"], g[p + "d"]
+        C = int(g[p + "classes"])
+        R, S = z.shape
+        if S == 1:
+            continue   # raw2outputs degenerates for one sample (custom_functions.py:300-301 yields an empty dists)
+        dists = np.concatenate([z[:, 1:] - z[:, :-1], np.full((R, 1), 1e10, np.float32)], -1)
+        dists = (dists * np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+        rays_a = np.stack([np.arange(R), np.arange(R) * S, np.full(R, S)], 1).astype(np.int64)
+        flat = raw.reshape(R * S, -1)
+        sems = flat[:, 10:] if C > 0 else np.zeros((R * S, 0), np.float32)
+        total, opacity, depth, rgb, normal, sem, ws = ngp.vren.composite_train_fw(
+            T(flat[:, 0]), T(flat[:, 1:4]), T(flat[:, 7:10]), T(sems), T(dists.reshape(-1)), T(z.reshape(-1)), T(rays_a),
+            0.0, C)
+        # raw2outputs adds 1e-10 inside the cumprod (custom_functions.py:311); the kernel uses __expf
+        close(N(opacity), g[p + "opacity"], 1e-4, 1e-5)
+        close(N(rgb), g[p + "rgb"], 1e-4, 1e-5)
+        close(N(normal), g[p + "normal_pred"], 1e-4, 1e-5)
+        close(N(depth), g[p + "depth"], 1e-4, 1e-5)
+        close(N(ws).reshape(R, S), g[p + "ws"], 1e-4, 1e-6)
+        if C:
+            close(N(sem), g[p + "sem"], 1e-4, 1e-5)
+        checked += 1
+    assert checked >= 10
+
+
+def test_package_activations_match_reference_golden_on_gpu(ngp, golden):
+    """TruncExp / ReLU / TruncTanh of the package on device tensors against the reference's classes (G4)"""
+    g = golden("g4_activations.npz")
+    cf = ngp.custom_functions
+    for name, fn in (("trunc_exp", cf.TruncExp), ("relu", cf.ReLU), ("trunc_tanh", cf.TruncTanh)):
+        x = T(g["x"]).clone().requires_grad_(True)
+        y = fn.apply(x)
+        y.backward(T(g["g"]))
+        close(N(y), g[name + "_y"], 2e-6, 0)
+        close(N(x.grad), g[name + "_dx"], 2e-6, 0)
+
+
+def test_raymarcher_backward_matches_reference_golden(ngp, golden):
+    """RayMarcher.backward (custom_functions.py:104-114) through the HIP segment_csr against the reference's own
+    method run on torch_scatter semantics (G5): rays with 0, 1 and several samples"""
+    g = golden("g5_raymarcher_bw.npz")
+
+    class Ctx:
+        saved_tensors = (T(g["rays_a"]), T(g["ts"]))
+
+    out = ngp.custom_functions.RayMarcher.backward(Ctx, None, T(g["dL_dxyzs"]), T(g["dL_ddirs"]), None, None, None)
+    close(N(out[0]), g["dL_drays_o"], 1e-6, 1e-6)
+    close(N(out[1]), g["dL_drays_d"], 1e-6, 1e-6)
+    assert all(o is None for o in out[2:])
+
+
+def test_tonemapper_and_exposure_match_reference_golden(ngp, golden):
+    """M4: NGP(rgb_act='None') — log-radiance -> TruncExp (output_radiance) or the three tone-mapper networks,
+    with and without a per-sample exposure — against the reference's own class (G13; the tone-mapping method is
+    models/networks_noCUDA.py:238-259 bound onto models/networks.py::NGP, which calls it without defining it)."""
+    from helpers import table_rule
+    g = golden("g13_tonemapper.npz")
+    model = ngp.networks.NGP(scale=0.5, rgb_act='None').to(DEV)
+    with torch.no_grad():
+        named = dict(model.named_parameters())
+        named["xyz_encoder.params"].copy_(T(table_rule(named["xyz_encoder.params"].numel())))
+        named["rgb_encoder.params"].copy_(T(table_rule(named["rgb_encoder.params"].numel())))
+        for k in g.files:
+            if k in named:
+                named[k].copy_(T(g[k]))
+        x, d = T(g["x"]), T(g["d"])
+        for tag, kw in (("radiance", {"output_radiance": True}), ("ldr", {}), ("ldr_exposure", {"exposure": T(g["exposure"])})):
+            sig, rgb = model(x, d, **kw)[:2]
+            rgb_t = model.forward_test(x, d, **kw)[1]
+            close(N(sig), g[f"fwd_{tag}_sigmas"], 2e-4, 1e-5)
+            close(N(rgb), g[f"fwd_{tag}_rgbs"], 5e-4, 1e-5)
+            close(N(rgb_t), g[f"test_{tag}_rgbs"], 5e-4, 1e-5)
+        unit = model.log_radiance_to_rgb(torch.zeros(1, 3, device=DEV), exposure=torch.ones(1, 1, device=DEV))
+        close(N(unit), g["unit_exposure_rgb"], 1e-5, 1e-6)
+    # and the tone-mapped colour trains: gradients reach the tone-mapper and rgb_net parameters
+    sig, rgb = model(x, d, exposure=T(g["exposure"]))[:2]
+    rgb.square().sum().backward()
+    assert model.tonemapper_net_0.params.grad.abs().sum() > 0 and model.rgb_net.params.grad.abs().sum() > 0
+
+
+def test_nerfloss_all_terms_match_reference_golden(ngp, golden):
+    """NeRFLoss with every optional term on (normal_ref, normal_mono, semantic + sky_depth, depth_mono) plus the HIP
+    distortion loss, values and the gradients of sum(term.mean()), against the reference's own losses.py (G14)"""
+    from ngp_amd.losses import NeRFLoss
+    g = golden("g14_loss_terms.npz")
+    res = {k[3:]: T(g[k]) for k in g.files if k.startswith("in_")}
+    tgt = {k[4:]: T(g[k]) for k in g.files if k.startswith("tgt_")}
+    diff = ("rgb", "opacity", "depth", "normal_pred", "semantic", "ws", "Ro", "Rp")
+    for k in diff:
+        res[k].requires_grad_(True)
+    out = NeRFLoss()(res, tgt, normal_ref=True, normal_mono=True, semantic=True, depth_mono=True,
+                     scale=float(g["scene_scale"]))
+    assert {"term_" + k for k in out} == {k for k in g.files if k.startswith("term_")}
+    for k, v in out.items():
+        close(N(v), g["term_" + k], 2e-5, 1e-7)
+    loss = sum(v.mean() for v in out.values())
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    for k in diff:
+        close(N(res[k].grad), g["grad_" + k], 2e-5, 1e-9)
+
+
+def test_volume_renderer_partial_coverage_zero_fills(ngp):
+    """A rays_a that covers a strict subset of the sample rows (a caller trimmed segments / dropped rays): the
+    VolumeRenderer Function must behave like vren.composite_train_fw/bw, i.e. like the reference's torch::zeros
+    outputs (volumerendering.cu:137-143, 280-283) — uncovered rows are exact zeros, forward and backward."""
+    g = rng(77)
+    rays_a, _n, sig, deltas, ts, rgbs, nrm, sems = _composite_inputs(40, 30, 7, 78)
+    keep = np.arange(0, 40, 3)
+    sub = rays_a[keep].copy()
+    sub[:, 2] = np.maximum(sub[:, 2] - 2, 0)            # trimmed segments: tails uncovered as well
+    sub[:, 0] = np.arange(len(keep))                    # ray ids 0..n-1 of the subset
+    args = [T(a) for a in (sig, rgbs, nrm, sems, deltas, ts)]
+    for a in args[:4]:
+        a.requires_grad_(True)
+    ra = T(sub)
+    outs = ngp.custom_functions.VolumeRenderer.apply(*args, ra, 1e-4, 7)
+    ref = ngp.vren.composite_train_fw(*[a.detach() for a in args], ra, 1e-4, 7)
+    for a, b in zip(outs[1:], ref[1:]):
+        assert torch.equal(a.detach(), b)
+    covered = np.zeros(len(sig), bool)
+    for _, s, n in sub:
+        covered[s:s + n] = True
+    assert (~covered).sum() > 100 and not N(outs[6])[~covered].any()
+    up = [T(g.normal(size=tuple(o.shape)).astype(np.float32)) for o in outs[1:]]
+    torch.autograd.backward(list(outs[1:]), up)
+    gref = ngp.vren.composite_train_bw(up[0], up[1], up[2], up[3], up[4], up[5], *[a.detach() for a in args[:3]],
+                                       outs[6].detach(), args[4], args[5], ra, outs[1].detach(), outs[2].detach(),
+                                       outs[3].detach(), outs[4].detach(), 1e-4, 7)
+    for a, b in zip(args[:4], gref):
+        assert torch.equal(a.grad, b)
+        assert not N(a.grad)[~covered].any()
+
+
+def test_trainer_checkpoint_roundtrip_and_optional_losses(ngp, tmp_path):
+    """(f)3: save_ckpt -> slim_ckpt -> NGPTrainer.load_ckpt into a flat-buffer trainer: the loaded values are the
+    ones the next optimizer step starts from (parameters stay within one Adam step of the checkpoint, not of the
+    fresh initialisation).  Then the loss_kwargs route of the trainer (train.py:289-300): normal_mono + semantic
+    targets through NGPTrainer.step."""
+    from ngp_amd import ckpt
+    from ngp_amd.trainer import NGPTrainer
+
+    def build(seed):
+        torch.manual_seed(seed)
+        m = ngp.networks.NGP(scale=0.5).to(DEV)
+        G = m.grid_size
+        m.register_buffer("density_grid", torch.zeros(m.cascades, G ** 3, device=DEV))
+        c = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=DEV)] * 3, indexing="ij"), -1)
+        m.register_buffer("grid_coords", c.reshape(-1, 3).contiguous())
+        return m
+
+    src = build(1)
+    small = ("xyz_net.0.weight", "xyz_net.2.weight", "rgb_net.params")
+    with torch.no_grad():
+        for k, p in src.named_parameters():
+            if k in small:
+                p.fill_(0.37)                      # far from any initialisation
+    path, slim_path = str(tmp_path / "last.ckpt"), str(tmp_path / "last_slim.ckpt")
+    ckpt.save_ckpt(src, path)
+    torch.save({"state_dict": ckpt.slim_ckpt(path)}, slim_path)
+    model = build(2)
+    tr = NGPTrainer(model, lr=1e-2)
+    flat_ptr = tr.flat_param.data_ptr()
+    tr.load_ckpt(slim_path)
+    assert tr.flat_param.data_ptr() == flat_ptr
+    for (k, p), (_, q) in zip(src.named_parameters(), model.named_parameters()):
+        assert torch.equal(p, q), k
+    model.update_density_grid(0.01 * 1024 / 3 ** 0.5, warmup=True)
+    g = rng(5)
+    n_rays = 1024
+    o = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=DEV), dim=-1) * 1.5
+    d = torch.nn.functional.normalize(-o + 0.2 * torch.randn(n_rays, 3, device=DEV), dim=-1)
+    gt = torch.rand(n_rays, 3, device=DEV)
+    tr.global_step = 1                             # no grid update inside the step
+    tr.step(o, d, gt)
+    tr.wait()
+    torch.cuda.synchronize()
+    named = dict(model.named_parameters())
+    for k in small:
+        dist = (named[k] - 0.37).abs().max().item()
+        assert dist <= 1.01e-2, (k, dist)          # one Adam step (lr 1e-2) away from the CHECKPOINT values
+    # optional loss terms through the trainer
+    tr2 = NGPTrainer(model, lr=1e-2, loss_kwargs={"normal_mono": True, "semantic": True})
+    assert not tr2.fused_loss
+    tr2.global_step = 1
+    target = {"normal": T(g.normal(size=(n_rays, 3)).astype(np.float32)),
+              "label": torch.randint(0, 7, (n_rays,), device=DEV)}
+    before = model.semantic_header.params.detach().clone()
+    loss, _ = tr2.step(o, d, gt, target=target)
+    tr2.wait()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and not torch.equal(before, model.semantic_header.params)
+    # normal_ref: the trainer switches the field to differentiable normals; without that NeRFLoss refuses
+    tr3 = NGPTrainer(model, lr=1e-2, loss_kwargs={"normal_ref": True})
+    assert model.differentiable_normals and not tr3.fused_loss
+    tr3.global_step = 1
+    loss, _ = tr3.step(o, d, gt)
+    tr3.wait()
+    assert torch.isfinite(loss)
+    model.differentiable_normals = False
+    with pytest.raises(RuntimeError, match="differentiable_normals"):
+        tr3.step(o, d, gt)
