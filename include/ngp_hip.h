@@ -98,6 +98,23 @@ int ngp_packbits(const float* density_grid, int n_bytes, float threshold, const 
  * xyzs_w[i] = (coords[i]/(G-1)*2-1)*(s-s/G) + (noise[i]*2-1)*s/G  (noise in [0,1))   */
 int ngp_grid_cell_points(const int32_t* coords, const float* noise, int n, int grid_size,
                          float s, float* xyzs_w, void* stream);
+/* The sampled branch of NGP.update_density_grid, fused (networks.py:308-333 + 388-398): for ONE cascade, m uniformly
+ * random cells + m cells drawn uniformly from the occupied ones (density_grid_c > density_threshold; none
+ * occupied: the m uniform ones only), in Morton bucket order, with their jittered world points
+ * x_w = (coord/(G-1)*2-1)*(s-s/G) + U(-1,1)*s/G.  Randomness is a counter-based hash of (seed, sample, draw): the
+ * same on every rank, independent of launch order.  workspace: ngp_grid_sample_workspace(G, m) int32 elements
+ * (host-only query).  outputs: indices (2m) i32 Morton cell indices, xyzs_w (2m,3) f32. */
+int64_t ngp_grid_sample_workspace(int grid_size, int m);
+int ngp_grid_sample_cells(const float* density_grid_c, int grid_size, float density_threshold, int m,
+                          int64_t seed, float s, int32_t* workspace, int32_t* indices, float* xyzs_w,
+                          void* stream);
+/* density_grid_tmp[c, indices] = sigmas (networks.py:398); several samples in one cell: the largest wins */
+int ngp_density_grid_scatter_max(float* density_grid_tmp_c, const int32_t* indices, const float* sigmas, int n,
+                                 void* stream);
+/* EMA as ngp_density_grid_ema, plus threshold_out[0] = min(mean of the positive cells, density_threshold) and
+ * threshold_out[1] = that mean (networks.py:405-407), kept on the device for ngp_packbits; partials: 1024 floats */
+int ngp_density_grid_ema_threshold(float* density_grid, const float* density_grid_tmp, int n, float decay,
+                                   float density_threshold, float* partials, float* threshold_out, void* stream);
 /* grid = grid<0 ? grid : max(grid*decay, tmp)  (networks.py:400-403), n = K*G^3 */
 int ngp_density_grid_ema(float* density_grid, const float* density_grid_tmp, int n,
                          float decay, void* stream);
@@ -268,6 +285,12 @@ int ngp_grid_fwd(const ngp_grid_desc* desc /* host */, const float* table, const
 /* dtable[(off+idx)*F+f] += w * dL_dy  (atomic fp32 scatter-add; caller zeroes dtable) */
 int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* dL_dy, int64_t lddy,
                        int64_t n, float* dtable, void* stream);
+/* Same, with every sample's gradient row multiplied by row_scale[sample] (NULL = 1) as it is loaded:
+ * dParam += w * row_scale[s] * dL_dy[s].  The density head has ONE output, so the gradient it sends into its
+ * encoder is a per-sample multiple of d(sigma)/d(features) — which the forward pass already computed for the
+ * analytic normals (networks.py:186-196): the backward needs no second data-gradient product. */
+int ngp_grid_bwd_param_scaled(const ngp_grid_desc* desc, const float* x, const float* dL_dy, int64_t lddy,
+                              const float* row_scale, int64_t n, float* dtable, void* stream);
 
 /* dL_dx (n,3) = sum_l d enc_l / dx . dL_dy_l */
 int ngp_grid_bwd_input(const ngp_grid_desc* desc, const float* table, const float* x,

@@ -329,6 +329,7 @@ __global__ void __launch_bounds__(256) grid_bwd_param_merge2_kernel(GridMeta met
 template <int F, int CHUNK>
 __global__ void __launch_bounds__(256) grid_bwd_param_slide_kernel(GridMeta meta, const float* __restrict__ x,
                                                                    const float* __restrict__ dL_dy, int64_t lddy,
+                                                                   const float* __restrict__ row_scale,
                                                                    int64_t n, float* __restrict__ dtable)
 {
     constexpr int LV = 64 / (2 * F);  // levels per wave
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(256) grid_bwd_param_slide_kernel(GridMeta meta
 #pragma unroll
         for (int j = 0; j < SUB; j++) {
             const int64_t s = sb + j < s1 ? sb + j : s1 - 1;
-            g[j] = active ? dL_dy[(size_t)s * ld + level * F + f] : 0.0f;
+            g[j] = active ? dL_dy[(size_t)s * ld + level * F + f] * (row_scale ? row_scale[s] : 1.0f) : 0.0f;
             px[j] = x[3 * s]; py[j] = x[3 * s + 1]; pz[j] = x[3 * s + 2];
         }
 #pragma unroll
@@ -435,6 +436,7 @@ __global__ void __launch_bounds__(256) grid_bwd_param_slide_kernel(GridMeta meta
 template <int CHUNK>
 __global__ void __launch_bounds__(256) grid_bwd_param_line_kernel(GridMeta meta, const float* __restrict__ x,
                                                                   const float* __restrict__ dL_dy, int64_t lddy,
+                                                                  const float* __restrict__ row_scale,
                                                                   int64_t n, float* __restrict__ dtable)
 {
     constexpr int F = 8;
@@ -492,7 +494,7 @@ __global__ void __launch_bounds__(256) grid_bwd_param_line_kernel(GridMeta meta,
 #pragma unroll
         for (int j = 0; j < SUB; j++) {
             const int64_t s = sb + j < s1 ? sb + j : s1 - 1;
-            g[j] = active ? dL_dy[(size_t)s * ld + level * F + f] : 0.0f;
+            g[j] = active ? dL_dy[(size_t)s * ld + level * F + f] * (row_scale ? row_scale[s] : 1.0f) : 0.0f;
             px[j] = x[3 * s]; py[j] = x[3 * s + 1]; pz[j] = x[3 * s + 2];
         }
 #pragma unroll
@@ -885,6 +887,12 @@ int ngp_grid_fwd(const ngp_grid_desc* desc, const float* table, const float* x, 
 int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* dL_dy, int64_t lddy, int64_t n,
                        float* dtable, void* stream)
 {
+    return ngp_grid_bwd_param_scaled(desc, x, dL_dy, lddy, nullptr, n, dtable, stream);
+}
+
+int ngp_grid_bwd_param_scaled(const ngp_grid_desc* desc, const float* x, const float* dL_dy, int64_t lddy,
+                              const float* row_scale, int64_t n, float* dtable, void* stream)
+{
     GridMeta m;
     if (!make_meta(desc, m) || n < 0) return NGP_EINVAL;
     if (n > 0 && lddy < (int64_t)m.n_levels * m.n_features) return NGP_EINVAL;
@@ -902,6 +910,7 @@ int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* d
         static const int lds_pad = getenv("NGP_SCATTER_LDS") ? atoi(getenv("NGP_SCATTER_LDS")) : 0;
         constexpr int LV = 64 / F;
         const int64_t waves = ((n + CHUNK - 1) / CHUNK) * ((m.n_levels + LV - 1) / LV);
+        if (variant != 0 && variant != 4 && row_scale) return NGP_EINVAL;   // the superseded variants take no row scale
         if (variant == 1) {
             const int64_t n_items = n * m.n_levels;
             hipLaunchKernelGGL(grid_bwd_param_kernel<F>, dim3(ngp_blocks(n_items * F, 256)), dim3(256), 0, st, m, x,
@@ -923,10 +932,10 @@ int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* d
             const int64_t w = ((n + line_chunk - 1) / line_chunk) * ((m.n_levels + 3) / 4);
             if (line_chunk == 64)
                 hipLaunchKernelGGL(grid_bwd_param_line_kernel<64>, dim3(ngp_blocks(w * 64, 256)), dim3(256), 0, st, m, x,
-                                   dL_dy, lddy, n, dtable);
+                                   dL_dy, lddy, row_scale, n, dtable);
             else
                 hipLaunchKernelGGL(grid_bwd_param_line_kernel<128>, dim3(ngp_blocks(w * 64, 256)), dim3(256), 0, st, m, x,
-                                   dL_dy, lddy, n, dtable);
+                                   dL_dy, lddy, row_scale, n, dtable);
             return ngp_check_launch();
         }
         const bool line = F == 8 && variant == 0;
@@ -935,10 +944,10 @@ int ngp_grid_bwd_param(const ngp_grid_desc* desc, const float* x, const float* d
 #endif
         if (line)    // F = 8 (the reference's tables): accumulate per 64-byte line
             hipLaunchKernelGGL(grid_bwd_param_line_kernel<CHUNK>, dim3(ngp_blocks(waves2 * 64, 256)), dim3(256), 0, st,
-                               m, x, dL_dy, lddy, n, dtable);
+                               m, x, dL_dy, lddy, row_scale, n, dtable);
         else
             hipLaunchKernelGGL((grid_bwd_param_slide_kernel<F, CHUNK>), dim3(ngp_blocks(waves2 * 64, 256)), dim3(256),
-                               0, st, m, x, dL_dy, lddy, n, dtable);
+                               0, st, m, x, dL_dy, lddy, row_scale, n, dtable);
     });
     return ngp_check_launch();
 }

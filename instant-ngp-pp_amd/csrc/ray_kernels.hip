@@ -150,6 +150,271 @@ __global__ void cell_points_kernel(const int32_t* __restrict__ coords, const flo
     out[i] = c * (s - hgs) + (noise[i] * 2 - 1) * hgs;
 }
 
+// ---- sampled occupancy update, fused (networks.py:308-333, 388-405) ---------------------------------------
+// M uniformly random cells + M cells drawn uniformly from the occupied ones, their jittered world points, a
+// Morton bucket order (gather locality of the density evaluation that follows), scatter of the densities back
+// and EMA + mean-of-positive-cells + threshold: 8 launches instead of ~70 torch ones.  All randomness comes
+// from a counter-based hash of (seed, sample id, draw), so the result does not depend on launch order and is
+// the same on every data-parallel rank.
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint32_t id, uint32_t draw)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)id * 8u + draw + 1u);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ uint32_t rand_below(uint64_t seed, uint32_t id, uint32_t draw, uint32_t n)
+{
+    return (uint32_t)(((uint64_t)hash_u32(seed, id, draw) * n) >> 32);
+}
+
+// cells per block of the occupancy count / compaction kernels: 256 lanes x 4 cells
+#define OCC_BLOCK 1024
+
+__device__ __forceinline__ int occ_mask4(const float* __restrict__ grid, int g3, int base, float thr)
+{
+    int m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (base + j < g3 && grid[base + j] > thr) m |= 1 << j;
+    return m;
+}
+
+__global__ void __launch_bounds__(256) occ_count_kernel(const float* __restrict__ grid, int g3, float thr,
+                                                        int32_t* __restrict__ block_counts)
+{
+    __shared__ int part[4];
+    const int base = blockIdx.x * OCC_BLOCK + threadIdx.x * 4;
+    int c = __popc(occ_mask4(grid, g3, base, thr));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// exclusive scan of `n` counts by ONE 1024-thread block: offsets[i] = sum of counts[0..i), total[0] = the sum;
+// also clears `clear_n` ints at `clear` (the bucket cursors of the next pass)
+__global__ void __launch_bounds__(1024) scan_counts_kernel(const int32_t* __restrict__ counts, int n,
+                                                           int32_t* __restrict__ offsets, int32_t* __restrict__ total,
+                                                           int32_t* __restrict__ clear, int clear_n)
+{
+    __shared__ int wsum[16];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    int s = 0;
+    for (int i = lo; i < hi; i++) s += counts[i];
+    // exclusive scan of the 1024 thread sums: inside each wave by shuffles, across the 16 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; w++) woff += wsum[w];
+    int run = woff + inc - s;
+    for (int i = lo; i < hi; i++) { offsets[i] = run; run += counts[i]; }
+    if (threadIdx.x == 1023 && total) total[0] = woff + inc;
+    for (int i = threadIdx.x; i < clear_n; i += 1024) clear[i] = 0;
+}
+
+__global__ void __launch_bounds__(256) occ_compact_kernel(const float* __restrict__ grid, int g3, float thr,
+                                                          const int32_t* __restrict__ block_offsets,
+                                                          int32_t* __restrict__ occ_list)
+{
+    __shared__ int wsum[4];
+    const int base = blockIdx.x * OCC_BLOCK + threadIdx.x * 4;
+    const int m = occ_mask4(grid, g3, base, thr);
+    const int c = __popc(m);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int pos = block_offsets[blockIdx.x] + inc - c;
+    for (int w = 0; w < wave; w++) pos += wsum[w];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (m & (1 << j)) occ_list[pos++] = base + j;     // ascending cell (= Morton) index
+}
+
+// Morton order of the samples matters: the density evaluation that follows gathers 128 hash-table rows per
+// point, and neighbouring points share them.  A two-level counting sort: 256 top-level buckets (the key's high
+// bits; per-block LDS histograms keep the global atomics at one per bucket and block), then one workgroup per
+// bucket orders it by the next 13 bits in LDS.
+#define SAMPLE_TOP_BITS 8
+#define SAMPLE_TOP (1 << SAMPLE_TOP_BITS)
+#define SAMPLE_SUB_BITS 13
+#define SAMPLE_SUB (1 << SAMPLE_SUB_BITS)
+#define SAMPLE_CHUNK 4096          // samples per 256-thread block in the histogram / scatter passes
+
+// sample i < m: a uniformly random cell; sample m + j: the k-th occupied cell, k uniform in [0, n_occ) — with no
+// occupied cell at all (the reference then samples the m uniform ones only, networks.py:326-329) it repeats
+// sample j exactly, which adds nothing.  keys = Morton index, sids = the id that seeds the sample's jitter.
+__global__ void __launch_bounds__(256) sample_cells_kernel(const int32_t* __restrict__ occ_list,
+                                                           const int32_t* __restrict__ n_occ_p, int G, int m,
+                                                           uint64_t seed, int shift, int32_t* __restrict__ keys,
+                                                           int32_t* __restrict__ sids, int32_t* __restrict__ bucket_counts)
+{
+    __shared__ int hist[SAMPLE_TOP];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int n_occ = *n_occ_p;
+    const int lo = blockIdx.x * SAMPLE_CHUNK;
+    for (int i = lo + threadIdx.x; i < lo + SAMPLE_CHUNK && i < 2 * m; i += 256) {
+        int sid = i;
+        uint32_t key;
+        if (i >= m && n_occ > 0) {
+            key = (uint32_t)occ_list[rand_below(seed, (uint32_t)i, 3, (uint32_t)n_occ)];
+        } else {
+            if (i >= m) sid = i - m;
+            key = morton_enc(rand_below(seed, (uint32_t)sid, 0, (uint32_t)G), rand_below(seed, (uint32_t)sid, 1, (uint32_t)G),
+                             rand_below(seed, (uint32_t)sid, 2, (uint32_t)G));
+        }
+        keys[i] = (int32_t)key; sids[i] = sid;
+        atomicAdd(&hist[key >> shift], 1);
+    }
+    __syncthreads();
+    if (hist[threadIdx.x]) atomicAdd(bucket_counts + threadIdx.x, hist[threadIdx.x]);
+}
+
+// scatter into the top-level buckets: one reservation per (block, bucket), positions inside it by LDS atomics
+__global__ void __launch_bounds__(256) bucket_scatter_kernel(const int32_t* __restrict__ keys, const int32_t* __restrict__ sids,
+                                                             int n, int shift, const int32_t* __restrict__ bucket_offsets,
+                                                             int32_t* __restrict__ bucket_cursor,
+                                                             int32_t* __restrict__ keys_b, int32_t* __restrict__ sids_b)
+{
+    __shared__ int hist[SAMPLE_TOP], base[SAMPLE_TOP];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int lo = blockIdx.x * SAMPLE_CHUNK;
+    for (int i = lo + threadIdx.x; i < lo + SAMPLE_CHUNK && i < n; i += 256) atomicAdd(&hist[(uint32_t)keys[i] >> shift], 1);
+    __syncthreads();
+    const int c = hist[threadIdx.x];
+    base[threadIdx.x] = bucket_offsets[threadIdx.x] + (c ? atomicAdd(bucket_cursor + threadIdx.x, c) : 0);
+    __syncthreads();
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < lo + SAMPLE_CHUNK && i < n; i += 256) {
+        const uint32_t key = (uint32_t)keys[i];
+        const uint32_t b = key >> shift;
+        const int pos = base[b] + atomicAdd(&hist[b], 1);
+        keys_b[pos] = (int32_t)key; sids_b[pos] = sids[i];
+    }
+}
+
+// one workgroup per top-level bucket: counting sort by the next SAMPLE_SUB_BITS key bits in LDS, then the
+// jittered world point of every sample: x_w = (coord/(G-1)*2-1)*(s - s/G) + (u*2-1)*s/G, u in [0,1)  (networks.py:391-395)
+__global__ void __launch_bounds__(1024) bucket_sort_points_kernel(const int32_t* __restrict__ keys_b, const int32_t* __restrict__ sids_b,
+                                                                  const int32_t* __restrict__ bucket_offsets, int n, int sub_shift,
+                                                                  int G, float s, uint64_t seed,
+                                                                  int32_t* __restrict__ out_idx, float* __restrict__ out_xyz)
+{
+    __shared__ int bins[SAMPLE_SUB];
+    __shared__ int wsum[16];
+    const int b = blockIdx.x;
+    const int lo = bucket_offsets[b], hi = b + 1 < SAMPLE_TOP ? bucket_offsets[b + 1] : n;
+    for (int i = threadIdx.x; i < SAMPLE_SUB; i += 1024) bins[i] = 0;
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < hi; i += 1024) atomicAdd(&bins[((uint32_t)keys_b[i] >> sub_shift) & (SAMPLE_SUB - 1)], 1);
+    __syncthreads();
+    // exclusive scan of the bins: 8 per thread, wave scan, 16 wave totals
+    constexpr int PER = SAMPLE_SUB / 1024;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { loc[k] = bins[threadIdx.x * PER + k]; sum += loc[k]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int run = lo + inc - sum;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < PER; k++) { bins[threadIdx.x * PER + k] = run; run += loc[k]; }
+    __syncthreads();
+    const float hgs = s / G;
+    for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+        const uint32_t key = (uint32_t)keys_b[i];
+        const uint32_t sid = (uint32_t)sids_b[i];
+        const int pos = atomicAdd(&bins[(key >> sub_shift) & (SAMPLE_SUB - 1)], 1);
+        out_idx[pos] = (int32_t)key;
+        const uint32_t c[3] = { compact3(key), compact3(key >> 1), compact3(key >> 2) };
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float u = (float)(hash_u32(seed, sid, 4 + k) >> 8) * (1.0f / 16777216.0f);
+            const float cc = (float)c[k] / (float)(G - 1) * 2 - 1;
+            out_xyz[3 * (size_t)pos + k] = cc * (s - hgs) + (u * 2 - 1) * hgs;
+        }
+    }
+}
+
+// tmp[idx[i]] = max(tmp[idx[i]], sigma[i]) — densities are positive (Softplus), so the int compare orders them;
+// with several samples in one cell the reference keeps whichever index_put wrote last: the largest is one of them
+__global__ void __launch_bounds__(256) grid_scatter_max_kernel(float* __restrict__ tmp, const int32_t* __restrict__ idx,
+                                                               const float* __restrict__ sigma, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = sigma[i];
+    if (v > 0.0f) atomicMax(reinterpret_cast<int*>(tmp) + idx[i], __float_as_int(v));
+}
+
+// EMA (networks.py:400-403) + per-block sum / count of the positive cells, in a fixed order (deterministic)
+__global__ void __launch_bounds__(256) grid_ema_stats_kernel(float* __restrict__ grid, const float* __restrict__ tmp, int n,
+                                                             float decay, float* __restrict__ partials)
+{
+    __shared__ float ps[4], pc[4];
+    float sum = 0.0f, cnt = 0.0f;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        float g = grid[i];
+        if (!(g < 0)) { g = fmaxf(g * decay, tmp[i]); grid[i] = g; }
+        if (g > 0) { sum += g; cnt += 1.0f; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); cnt += __shfl_xor(cnt, o, 64); }
+    if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = sum; pc[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        partials[2 * blockIdx.x + 1] = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+    }
+}
+
+// threshold = min(mean of the positive cells, density_threshold)  (networks.py:405-407); no positive cell: 0
+__global__ void __launch_bounds__(256) grid_threshold_kernel(const float* __restrict__ partials, int n_blocks,
+                                                             float density_threshold, float* __restrict__ thr_out)
+{
+    __shared__ double ps[4], pc[4];
+    double sum = 0.0, cnt = 0.0;
+    for (int i = threadIdx.x; i < n_blocks; i += 256) { sum += partials[2 * i]; cnt += partials[2 * i + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); cnt += __shfl_xor(cnt, o, 64); }
+    if ((threadIdx.x & 63) == 0) { ps[threadIdx.x >> 6] = sum; pc[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s = (ps[0] + ps[1]) + (ps[2] + ps[3]), c = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+        const float mean = c > 0 ? (float)(s / c) : 0.0f;
+        thr_out[0] = fminf(mean, density_threshold);
+        thr_out[1] = mean;
+    }
+}
+
 __global__ void grid_ema_kernel(float* __restrict__ grid, const float* __restrict__ tmp, int n, float decay)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -553,6 +818,88 @@ int ngp_grid_cell_points(const int32_t* coords, const float* noise, int n, int g
     if (!coords || !noise || !xyzs_w) return NGP_EINVAL;
     hipLaunchKernelGGL(cell_points_kernel, dim3(ngp_blocks((int64_t)n * 3, 256)), dim3(256), 0, (hipStream_t)stream,
                        coords, noise, n * 3, grid_size, s, xyzs_w);
+    return ngp_check_launch();
+}
+
+static int key_bits(int g3)
+{
+    int bits = 0;
+    while ((1ll << bits) < (long long)g3) bits++;
+    return bits;
+}
+
+int64_t ngp_grid_sample_workspace(int grid_size, int m)
+{
+    if (grid_size < 1 || grid_size > 1024 || m < 1) return NGP_EINVAL;
+    const int64_t g3 = (int64_t)grid_size * grid_size * grid_size;
+    const int64_t nb = (g3 + OCC_BLOCK - 1) / OCC_BLOCK;
+    return 2 * nb + 4 + g3 + 8 * (int64_t)m + 3 * SAMPLE_TOP;
+}
+
+int ngp_grid_sample_cells(const float* density_grid_c, int grid_size, float density_threshold, int m, int64_t seed,
+                          float s, int32_t* workspace, int32_t* indices, float* xyzs_w, void* stream)
+{
+    if (grid_size < 2 || grid_size > 1024 || m < 1) return NGP_EINVAL;
+    if (!density_grid_c || !workspace || !indices || !xyzs_w) return NGP_EINVAL;
+    const int64_t g3l = (int64_t)grid_size * grid_size * grid_size;
+    if (g3l > (1ll << 30) || 2 * (int64_t)m > (1ll << 30)) return NGP_EINVAL;
+    const int g3 = (int)g3l;
+    const int nb = (g3 + OCC_BLOCK - 1) / OCC_BLOCK;
+    const int bits = key_bits(g3);
+    const int shift = bits > SAMPLE_TOP_BITS ? bits - SAMPLE_TOP_BITS : 0;          // key >> shift = top-level bucket
+    const int sub_shift = shift > SAMPLE_SUB_BITS ? shift - SAMPLE_SUB_BITS : 0;    // next 13 bits order a bucket
+    int32_t* block_counts = workspace;
+    int32_t* block_offsets = block_counts + nb;
+    int32_t* n_occ = block_offsets + nb;            // 4 ints (alignment)
+    int32_t* occ_list = n_occ + 4;
+    int32_t* keys = occ_list + g3;
+    int32_t* sids = keys + 2 * (int64_t)m;
+    int32_t* keys_b = sids + 2 * (int64_t)m;
+    int32_t* sids_b = keys_b + 2 * (int64_t)m;
+    int32_t* bucket_counts = sids_b + 2 * (int64_t)m;
+    int32_t* bucket_offsets = bucket_counts + SAMPLE_TOP;
+    int32_t* bucket_cursor = bucket_offsets + SAMPLE_TOP;
+    const int n = 2 * m;
+    const unsigned chunks = ngp_blocks(n, SAMPLE_CHUNK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(occ_count_kernel, dim3(nb), dim3(256), 0, st, density_grid_c, g3, density_threshold, block_counts);
+    // the scan also clears the bucket histogram of the sampling pass
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, block_counts, nb, block_offsets, n_occ,
+                       bucket_counts, SAMPLE_TOP);
+    hipLaunchKernelGGL(occ_compact_kernel, dim3(nb), dim3(256), 0, st, density_grid_c, g3, density_threshold,
+                       block_offsets, occ_list);
+    hipLaunchKernelGGL(sample_cells_kernel, dim3(chunks), dim3(256), 0, st, occ_list, n_occ, grid_size, m,
+                       (uint64_t)seed, shift, keys, sids, bucket_counts);
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, bucket_counts, SAMPLE_TOP, bucket_offsets,
+                       (int32_t*)nullptr, bucket_cursor, SAMPLE_TOP);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(chunks), dim3(256), 0, st, keys, sids, n, shift, bucket_offsets,
+                       bucket_cursor, keys_b, sids_b);
+    hipLaunchKernelGGL(bucket_sort_points_kernel, dim3(SAMPLE_TOP), dim3(1024), 0, st, keys_b, sids_b, bucket_offsets, n,
+                       sub_shift, grid_size, s, (uint64_t)seed, indices, xyzs_w);
+    return ngp_check_launch();
+}
+
+int ngp_density_grid_scatter_max(float* density_grid_tmp_c, const int32_t* indices, const float* sigmas, int n, void* stream)
+{
+    if (n < 0) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!density_grid_tmp_c || !indices || !sigmas) return NGP_EINVAL;
+    hipLaunchKernelGGL(grid_scatter_max_kernel, dim3(ngp_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       density_grid_tmp_c, indices, sigmas, n);
+    return ngp_check_launch();
+}
+
+int ngp_density_grid_ema_threshold(float* density_grid, const float* density_grid_tmp, int n, float decay,
+                                   float density_threshold, float* partials, float* threshold_out, void* stream)
+{
+    if (n < 0) return NGP_EINVAL;
+    if (!threshold_out || !partials) return NGP_EINVAL;
+    if (n > 0 && (!density_grid || !density_grid_tmp)) return NGP_EINVAL;
+    const int blocks = 512;   // partials: 2 * 512 floats
+    hipLaunchKernelGGL(grid_ema_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, density_grid,
+                       density_grid_tmp, n, decay, partials);
+    hipLaunchKernelGGL(grid_threshold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, blocks,
+                       density_threshold, threshold_out);
     return ngp_check_launch();
 }
 

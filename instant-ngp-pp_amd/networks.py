@@ -23,7 +23,7 @@ from torch.autograd import Function
 
 from . import tinycudann as tcnn
 from . import vren
-from ._lib import call
+from ._lib import call, call_host
 from .custom_functions import TruncExp
 from .rendering import NEAR_DISTANCE
 
@@ -79,6 +79,8 @@ _FUSED_FWD = _os.environ.get("NGP_NO_FUSED_FWD", "0") != "1"   # A/B switch for 
 _FUSED_BWD = _os.environ.get("NGP_NO_FUSED_BWD", "0") != "1"   # A/B switch for the operand-transform products
 # the library's streaming weight-gradient kernel (mlp_stream_wgrad_kernel) is on unless one of its A/B switches is set
 _SORT_GRID_SAMPLES = _os.environ.get("NGP_NO_SORT_GRID_SAMPLES", "0") != "1"   # A/B: Morton-sorted occupancy-update points
+_REUSE_DSIG_DFEAT = _os.environ.get("NGP_NO_REUSE_DFEAT", "0") != "1"           # A/B: second data-gradient product of the density head
+_FUSED_GRID_UPDATE = _os.environ.get("NGP_GRID_UPDATE_TORCH", "0") != "1"       # A/B: the torch-op route of the sampled update
 _STREAM_WGRAD = not (_os.environ.get("NGP_MLP_NO_STREAM") or _os.environ.get("NGP_MLP_NO_STREAM_WGRAD"))
 # widest second layer that takes the fused route (tools/mlp_bwd_microbench.py, n = 433 k, MI355X):
 # density head 0.54 -> 0.49 ms, rgb_net 0.60 -> 0.57 ms, 32-wide headers 0.22 -> 0.22 ms
@@ -94,63 +96,79 @@ def _side_stream(dev):
     return st
 
 
-def _mlp2_backward(d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, ld_in, n_in, W1, ldw1, dW1, dW2,
-                   db1, db2, dx, ld_dx, dx_cols, w1_col0, accumulate, before_products=None):
-    """Backward of a 2-layer MLP (x_in -> H hidden with act1 -> n_out with act2) on the library:
-    dz2/dz1 by the fused hidden-backward kernel, three MFMA/VALU products for dW2, dW1 and dx.
-    dx receives dz1 . W1[:, w1_col0 : w1_col0+dx_cols] (the input columns that need a gradient)."""
-    n = hidden.shape[0]
-    dev = hidden.device
-    w1_dx = W1[w1_col0:] if W1.dim() == 1 else W1
-    wide = n_in > 128 and n_in % 128 <= 32
-    # 128 + remainder columns: a second launch with 128x32 tiles instead of a mostly empty 128x128
-    # tile (rgb_net's first layer is 128 x 144/160)
-    rem = n_in - 128
-    x_rem = x_in[:, 128:] if x_in.dim() == 2 else x_in
-    dW1_rem = dW1[128:] if dW1.dim() == 1 else dW1[:, 128:]
-    if _FUSED_BWD and n_out <= _FUSED_BWD_MAX_OUT and d_out.stride(0) == n_out and ld_out == n_out:
-        # dz1 = act1'(hidden) * (dz2 . W2) is formed inside the two first-layer products
-        dz2 = torch.empty(n, n_out, dtype=_f32, device=dev)
-        call("act_bwd", d_out, out, n * n_out, act2, dz2)
-        if before_products is not None:
-            before_products()
-        # the first-layer weight product streams dz2 and hidden anyway: it also leaves dW2 / db2
-        if wide and _STREAM_WGRAD and H == 128 and n_in in (144, 160) and act1 in (_RELU, _SOFTPLUS):
-            # the streaming kernel takes all 144 / 160 input columns (and dW2 / db2) in one pass
-            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, n_in, H, n_out, dW1, ldw1, db1,
-                 dW2, H, db2)
-        elif wide:
-            # dW2 / db2 ride with the narrow remainder launch (16 accumulator registers per lane; in the
-            # 128x128 one the extra partial sums would spill at 3 workgroups per CU)
-            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, 128, H, n_out, dW1, ldw1, db1,
-                 None, 0, None)
-            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_rem, ld_in, n, rem, H, n_out, dW1_rem, ldw1, None,
-                 dW2, H, db2)
+class _Mlp2Bwd:
+    """Backward of a 2-layer MLP (x_in -> H hidden with act1 -> n_out with act2) on the library, in three stages
+    the caller can interleave with other work: the constructor runs the elementwise stage (dz2, on the plain route
+    also dz1), input_product() the data gradient dz1 . W1[:, cols], weight_products() dW1 / dW2 / db1 / db2.
+    On the fused route dz1 = act1'(hidden) * (dz2 . W2) is formed inside the two first-layer products."""
+
+    def __init__(self, d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, ld_in, n_in, W1, ldw1, dW1, dW2,
+                 db1, db2):
+        self.a = (d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, ld_in, n_in, W1, ldw1, dW1, dW2, db1, db2)
+        n = hidden.shape[0]
+        dev = hidden.device
+        self.n = n
+        self.fused = bool(_FUSED_BWD and n_out <= _FUSED_BWD_MAX_OUT and d_out.stride(0) == n_out and ld_out == n_out)
+        self.dz1 = None
+        self.dw2_done = False
+        if self.fused:
+            self.dz2 = torch.empty(n, n_out, dtype=_f32, device=dev)
+            call("act_bwd", d_out, out, n * n_out, act2, self.dz2)
+            return
+        self.dz2 = torch.empty(n, 16 if n_out > 4 else 4, dtype=_f32, device=dev)
+        self.dz1 = torch.empty(n, H, dtype=_f32, device=dev)
+        if n_out <= 4:   # dW2 / db2 come out of the same pass over the hidden activations
+            call("mlp_hidden_bwd", d_out, d_out.stride(0), out, ld_out, act2, W2, H, hidden, H, act1, n, H, n_out,
+                 None, 0, self.dz1, H, dW2, H, db2)
+            self.dw2_done = True
         else:
-            call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, n_in, H, n_out, dW1, ldw1, db1,
-                 dW2, H, db2)
-        if dx is not None:
-            call("mlp_bwd_input", dz2, n_out, W2, H, hidden, H, act1, w1_dx, ldw1, n, dx_cols, H, n_out, dx, ld_dx,
+            call("mlp_hidden_bwd", d_out, d_out.stride(0), out, ld_out, act2, W2, H, hidden, H, act1, n, H, n_out,
+                 self.dz2, self.dz2.shape[1], self.dz1, H, None, 0, None)
+
+    def input_product(self, dx, ld_dx, dx_cols, w1_col0, accumulate):
+        """dx (+)= dz1 . W1[:, w1_col0 : w1_col0 + dx_cols] (the input columns that need a gradient)"""
+        (d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, ld_in, n_in, W1, ldw1, dW1, dW2, db1, db2) = self.a
+        w1_dx = W1[w1_col0:] if W1.dim() == 1 else W1
+        if self.fused:
+            call("mlp_bwd_input", self.dz2, n_out, W2, H, hidden, H, act1, w1_dx, ldw1, self.n, dx_cols, H, n_out, dx, ld_dx,
                  1 if accumulate else 0)
-        return
-    dz2 = torch.empty(n, 16 if n_out > 4 else 4, dtype=_f32, device=dev)
-    dz1 = torch.empty(n, H, dtype=_f32, device=dev)
-    if n_out <= 4:   # dW2 / db2 come out of the same pass over the hidden activations
-        call("mlp_hidden_bwd", d_out, d_out.stride(0), out, ld_out, act2, W2, H, hidden, H, act1, n, H, n_out,
-             None, 0, dz1, H, dW2, H, db2)
-    else:
-        call("mlp_hidden_bwd", d_out, d_out.stride(0), out, ld_out, act2, W2, H, hidden, H, act1, n, H, n_out,
-             dz2, dz2.shape[1], dz1, H, None, 0, None)
-        call("linear_bwd_weight", dz2, dz2.shape[1], hidden, H, n, H, n_out, dW2, H, db2)
-    if before_products is not None:
-        before_products()
-    if wide:
-        call("linear_bwd_weight", dz1, H, x_in, ld_in, n, 128, H, dW1, ldw1, db1)
-        call("linear_bwd_weight", dz1, H, x_rem, ld_in, n, rem, H, dW1_rem, ldw1, None)
-    else:
-        call("linear_bwd_weight", dz1, H, x_in, ld_in, n, n_in, H, dW1, ldw1, db1)
-    if dx is not None:
-        call("linear_bwd_input", dz1, H, w1_dx, ldw1, n, dx_cols, H, dx, ld_dx, 1 if accumulate else 0)
+        else:
+            call("linear_bwd_input", self.dz1, H, w1_dx, ldw1, self.n, dx_cols, H, dx, ld_dx, 1 if accumulate else 0)
+
+    def weight_products(self):
+        (d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, ld_in, n_in, W1, ldw1, dW1, dW2, db1, db2) = self.a
+        n = self.n
+        wide = n_in > 128 and n_in % 128 <= 32
+        # 128 + remainder columns: a second launch with 128x32 tiles instead of a mostly empty 128x128
+        # tile (rgb_net's first layer is 128 x 144/160)
+        rem = n_in - 128
+        x_rem = x_in[:, 128:] if x_in.dim() == 2 else x_in
+        dW1_rem = dW1[128:] if dW1.dim() == 1 else dW1[:, 128:]
+        if self.fused:
+            dz2 = self.dz2
+            # the first-layer weight product streams dz2 and hidden anyway: it also leaves dW2 / db2
+            if wide and _STREAM_WGRAD and H == 128 and n_in in (144, 160) and act1 in (_RELU, _SOFTPLUS):
+                # the streaming kernel takes all 144 / 160 input columns (and dW2 / db2) in one pass
+                call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, n_in, H, n_out, dW1, ldw1, db1,
+                     dW2, H, db2)
+            elif wide:
+                # dW2 / db2 ride with the narrow remainder launch (16 accumulator registers per lane; in the
+                # 128x128 one the extra partial sums would spill at 3 workgroups per CU)
+                call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, 128, H, n_out, dW1, ldw1, db1,
+                     None, 0, None)
+                call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_rem, ld_in, n, rem, H, n_out, dW1_rem, ldw1,
+                     None, dW2, H, db2)
+            else:
+                call("mlp_bwd_weight", dz2, n_out, W2, H, hidden, H, act1, x_in, ld_in, n, n_in, H, n_out, dW1, ldw1, db1,
+                     dW2, H, db2)
+            return
+        if not self.dw2_done:
+            call("linear_bwd_weight", self.dz2, self.dz2.shape[1], hidden, H, n, H, n_out, dW2, H, db2)
+        if wide:
+            call("linear_bwd_weight", self.dz1, H, x_in, ld_in, n, 128, H, dW1, ldw1, db1)
+            call("linear_bwd_weight", self.dz1, H, x_rem, ld_in, n, rem, H, dW1_rem, ldw1, None)
+        else:
+            call("linear_bwd_weight", self.dz1, H, x_in, ld_in, n, n_in, H, dW1, ldw1, db1)
 
 
 class _NegNormalize(Function):
@@ -244,7 +262,9 @@ class _FieldFn(Function):
             call("linear_bwd_input", dz1, 128, W1, 128, n, 128, 128, dfeat, 128, 0)
         grads = torch.empty(n, 3, dtype=_f32, device=dev)   # d sigma / d xn (normalised coordinates)
         call("grid_bwd_input", xe.desc, xyz_table, xn, dfeat, 128, n, grads)
-        del dz1, dfeat
+        del dz1
+        # dfeat = d(sigma)/d(features) is kept: the density head has ONE output, so the gradient the backward
+        # sends into the density encoder is d_sigma[s] * dfeat[s] — no second data-gradient product there
 
         # colour branch: [SH(16) | rgb grid features (128) | appearance code (E) | ones-padding]
         rgb_in = torch.empty(n, Kp, dtype=_f32, device=dev)
@@ -283,7 +303,7 @@ class _FieldFn(Function):
         ctx.model = model
         ctx.E, ctx.K, ctx.Kp, ctx.C = E, K, Kp, C
         ctx.save_for_backward(xn, feat, a1, sig, rgb_in, a_r, rgb_o, a_n, np_o, a_s, sem_o,
-                              xyz_table, W1, W2, rgb_table, rgb_p, nrm_p, sem_p)
+                              xyz_table, W1, W2, rgb_table, rgb_p, nrm_p, sem_p, dfeat)
         ctx.mark_non_differentiable(grads)
         ctx.set_materialize_grads(False)
         return sig[:, 0], rgb_o, grads, np_o, sem_o
@@ -291,7 +311,7 @@ class _FieldFn(Function):
     @staticmethod
     def backward(ctx, d_sig, d_rgb, _d_grads, d_np, d_sem):
         (xn, feat, a1, sig, rgb_in, a_r, rgb_o, a_n, np_o, a_s, sem_o,
-         xyz_table, W1, W2, rgb_table, rgb_p, nrm_p, sem_p) = ctx.saved_tensors
+         xyz_table, W1, W2, rgb_table, rgb_p, nrm_p, sem_p, dsig_dfeat) = ctx.saved_tensors
         model = ctx.model
         E, K, Kp, C = ctx.E, ctx.K, ctx.Kp, ctx.C
         n = xn.shape[0]
@@ -312,15 +332,56 @@ class _FieldFn(Function):
             z = torch.zeros(like, dtype=_f32, device=dev) if isinstance(like, tuple) else torch.zeros_like(like)
             return z, z
 
-        # ---- colour branch (rgb_net + the two heads) -> gradient w.r.t. [grid features | appearance code]
+        # Schedule.  The two table scatters are bound by memory-side atomic requests, the MLP products by the
+        # matrix pipe: the scatters go to a side stream, one behind the other, and the products run beside them.
+        #   side: [density scatter] -> [colour scatter (+ its share of the gradient norm / its reduce-scatter)]
+        #   main: colour data gradients -> (fork) -> colour weight gradients -> density weight gradients -> join
+        # The density scatter can start at once: its input is d_sigma[s] * d(sigma)/d(features)[s], and the second
+        # factor was computed (and kept) by the forward pass for the analytic normals.
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev) if _OVERLAP else None
+        forked = False
+
+        def on_side(fn):
+            nonlocal forked
+            if side is None:
+                fn()
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fn()
+            forked = True
+
+        def table_buffer(enc, table):
+            buf = getattr(enc, "grad_buffer", None)
+            if buf is None:
+                buf = torch.zeros_like(table)
+                return buf, buf
+            return buf, None
+
+        reuse = d_sig is not None and _REUSE_DSIG_DFEAT and not need[1]
+        if reuse and need[4]:
+            d_sig_c = d_sig.contiguous()
+            buf, g_xyz = table_buffer(xe, xyz_table)
+
+            def density_scatter():
+                call("grid_bwd_param_scaled", xe.desc, xn, dsig_dfeat, 128, d_sig_c, n, buf)
+                cb = getattr(xe, "on_grad_ready", None)
+                if cb is not None:
+                    cb()
+            on_side(density_scatter)
+
+        # ---- colour branch (rgb_net + the two heads): data gradients w.r.t. [grid features | appearance code] first
         dfeat_rgb = None
         W_cols = 128 + E
+        stages = []
         if d_rgb is not None:
             acc_rgbp, g_rgbp = grad_buffer("rgb_p", rgb_p)
             dfeat_rgb = torch.empty(n, W_cols, dtype=_f32, device=dev)
-            _mlp2_backward(d_rgb.contiguous(), rgb_o, 3, model.rgb_net.output_activation, rgb_p[128 * Kp:], a_r, 128,
-                           _RELU, 3, rgb_in, Kp, Kp, rgb_p, Kp, acc_rgbp, acc_rgbp[128 * Kp:], None, None,
-                           dfeat_rgb, W_cols, W_cols, 16, False)
+            st = _Mlp2Bwd(d_rgb.contiguous(), rgb_o, 3, model.rgb_net.output_activation, rgb_p[128 * Kp:], a_r, 128,
+                          _RELU, 3, rgb_in, Kp, Kp, rgb_p, Kp, acc_rgbp, acc_rgbp[128 * Kp:], None, None)
+            st.input_product(dfeat_rgb, W_cols, W_cols, 16, False)
+            stages.append(st)
         for d_o, p, a_h, out, n_out, slot in ((d_np, nrm_p, a_n, np_o, 3, "nrm"), (d_sem, sem_p, a_s, sem_o, C, "sem")):
             if d_o is None:
                 continue
@@ -328,76 +389,61 @@ class _FieldFn(Function):
             first = dfeat_rgb is None
             if first:
                 dfeat_rgb = torch.zeros(n, W_cols, dtype=_f32, device=dev) if E else torch.empty(n, W_cols, dtype=_f32, device=dev)
-            _mlp2_backward(d_o.contiguous(), out, n_out, _NONE, p[32 * 128:], a_h, 32, _RELU, n_out,
-                           rgb_in[:, 16:], Kp, 128, p, 128, acc_p, acc_p[32 * 128:], None, None,
-                           dfeat_rgb, W_cols, 128, 0, not first)
+            st = _Mlp2Bwd(d_o.contiguous(), out, n_out, _NONE, p[32 * 128:], a_h, 32, _RELU, n_out,
+                          rgb_in[:, 16:], Kp, 128, p, 128, acc_p, acc_p[32 * 128:], None, None)
+            st.input_product(dfeat_rgb, W_cols, 128, 0, not first)
+            stages.append(st)
             if slot == "nrm":
                 g_nrm = g_p
             else:
                 g_sem = g_p
 
-        # The colour-table scatter is bound by memory-side atomics; the density head's MFMA products
-        # are not.  The scatter is therefore forked onto a side stream right before those products
-        # (after the head's bandwidth-bound elementwise stage, which would only fight it for HBM) and
-        # joined at the end of backward.
-        forked = False
+        if dfeat_rgb is not None and need[9]:
+            buf_c, g_rgbt = table_buffer(re, rgb_table)
 
-        def colour_scatter():
-            nonlocal g_rgbt, forked
-            if dfeat_rgb is None or not need[9]:
-                return
-            buf = getattr(re, "grad_buffer", None)
-            if buf is None:
-                g_rgbt = torch.zeros_like(rgb_table)
-                buf = g_rgbt
-            cb = getattr(re, "on_grad_ready", None)
-            if _OVERLAP and d_sig is not None:
-                side = _side_stream(dev)
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    call("grid_bwd_param", re.desc, xn, dfeat_rgb, W_cols, n, buf)
-                    if cb is not None:
-                        cb()
-                forked = True
-            else:
-                call("grid_bwd_param", re.desc, xn, dfeat_rgb, W_cols, n, buf)
+            def colour_scatter():
+                call("grid_bwd_param", re.desc, xn, dfeat_rgb, W_cols, n, buf_c)
+                cb = getattr(re, "on_grad_ready", None)
                 if cb is not None:
                     cb()
-
+            if d_sig is not None:
+                on_side(colour_scatter)
+            else:
+                colour_scatter()
         if dfeat_rgb is not None:
             if E and need[3]:
                 g_emb = dfeat_rgb[:, 128:]
             if need[1]:
                 g_x = torch.empty(n, 3, dtype=_f32, device=dev)
                 call("grid_bwd_input", re.desc, rgb_table, xn, dfeat_rgb, W_cols, n, g_x)
+        for st in stages:
+            st.weight_products()
 
         # ---- density head
         if d_sig is not None:
             (acc_W1, g_W1), (acc_W2, g_W2) = grad_buffer("W1", W1), grad_buffer("W2", W2)
             (acc_b1, g_b1), (acc_b2, g_b2) = grad_buffer("b1", (128,)), grad_buffer("b2", (1,))
-            dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
-            _mlp2_backward(d_sig.contiguous().view(n, 1), sig, 1, _SOFTPLUS, W2, a1, 128, _SOFTPLUS, 1,
-                           feat, 128, 128, W1, 128, acc_W1, acc_W2, acc_b1, acc_b2, dfeat, 128, 128, 0, False,
-                           before_products=colour_scatter)
-            if need[4]:
-                buf = getattr(xe, "grad_buffer", None)
-                if buf is None:
-                    g_xyz = torch.zeros_like(xyz_table)
-                    buf = g_xyz
-                call("grid_bwd_param", xe.desc, xn, dfeat, 128, n, buf)
-                cb = getattr(xe, "on_grad_ready", None)
-                if cb is not None:
-                    cb()
-            if need[1]:
-                gx2 = torch.empty(n, 3, dtype=_f32, device=dev)
-                call("grid_bwd_input", xe.desc, xyz_table, xn, dfeat, 128, n, gx2)
-                g_x = gx2 if g_x is None else g_x + gx2
-        else:
-            colour_scatter()
+            st = _Mlp2Bwd(d_sig.contiguous().view(n, 1), sig, 1, _SOFTPLUS, W2, a1, 128, _SOFTPLUS, 1,
+                          feat, 128, 128, W1, 128, acc_W1, acc_W2, acc_b1, acc_b2)
+            if not reuse:
+                dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
+                st.input_product(dfeat, 128, 128, 0, False)
+            st.weight_products()
+            if not reuse:
+                if need[4]:
+                    buf, g_xyz = table_buffer(xe, xyz_table)
+                    call("grid_bwd_param", xe.desc, xn, dfeat, 128, n, buf)
+                    cb = getattr(xe, "on_grad_ready", None)
+                    if cb is not None:
+                        cb()
+                if need[1]:
+                    gx2 = torch.empty(n, 3, dtype=_f32, device=dev)
+                    call("grid_bwd_input", xe.desc, xyz_table, xn, dfeat, 128, n, gx2)
+                    g_x = gx2 if g_x is None else g_x + gx2
         if g_x is not None:
             g_x = g_x / span
         if forked:
-            torch.cuda.current_stream().wait_stream(_side_stream(dev))
+            main.wait_stream(side)
         return (None, g_x, None, g_emb, g_xyz, g_W1, g_b1, g_W2, g_b2, g_rgbt, g_rgbp, g_nrm, g_sem)
 
 
@@ -670,7 +716,43 @@ class NGP(nn.Module):
                 self.density_grid[c, sel] = torch.where((seen > 0) & ~too_close, 0.0, -1.0)
 
     @torch.no_grad()
+    def _update_density_grid_sampled(self, density_threshold, decay):
+        """The sampled branch of update_density_grid on the fused kernels (ngp_grid_sample_cells ->
+        density() -> ngp_density_grid_scatter_max -> ngp_density_grid_ema_threshold -> ngp_packbits): per
+        cascade M = G^3/4 uniform cells + M occupied ones, jittered, evaluated, max-combined into the grid; EMA,
+        mean threshold and bit packing.  The draws are a counter-based hash of (seed, update number, cascade):
+        identical on every data-parallel rank (the seed comes from `grid_rng` when the trainer set one)."""
+        G = self.grid_size
+        M = G ** 3 // 4
+        dev = self.density_grid.device
+        ws = getattr(self, '_grid_ws', None)
+        if ws is None or ws[0].device != dev:
+            n_ws = call_host("grid_sample_workspace", G, M)
+            ws = self._grid_ws = (torch.empty(n_ws, dtype=torch.int32, device=dev),
+                                  torch.empty(2 * M, dtype=torch.int32, device=dev),
+                                  torch.empty(2 * M, 3, dtype=_f32, device=dev),
+                                  torch.empty(1024, dtype=_f32, device=dev), torch.empty(2, dtype=_f32, device=dev))
+            gen = getattr(self, 'grid_rng', None)
+            self._grid_seed = int(gen.initial_seed() if gen is not None else torch.initial_seed()) & 0x7FFFFFFFFFFF
+            self._grid_updates = 0
+        work, indices, xyzs_w, partials, thr = ws
+        density_grid_tmp = torch.zeros_like(self.density_grid)
+        for c in range(self.cascades):
+            s = min(2 ** (c - 1), self.scale)
+            seed = self._grid_seed + 1000003 * self._grid_updates + 7919 * c
+            call("grid_sample_cells", self.density_grid[c], G, float(density_threshold), M, seed, float(s), work, indices,
+                 xyzs_w)
+            sig = self.density(xyzs_w)
+            call("density_grid_scatter_max", density_grid_tmp[c], indices, sig.contiguous(), 2 * M)
+        self._grid_updates += 1
+        call("density_grid_ema_threshold", self.density_grid, density_grid_tmp, self.density_grid.numel(), float(decay),
+             float(density_threshold), partials, thr)
+        call("packbits", self.density_grid.view(-1), self.density_bitfield.shape[0], 0.0, thr, self.density_bitfield)
+
+    @torch.no_grad()
     def update_density_grid(self, density_threshold, warmup=False, decay=0.95, erode=False):
+        if not warmup and not erode and _FUSED_GRID_UPDATE and self.density_grid.is_cuda:
+            return self._update_density_grid_sampled(density_threshold, decay)
         density_grid_tmp = torch.zeros_like(self.density_grid)
         if warmup:
             cells = self.get_all_cells()

@@ -1848,3 +1848,114 @@ def test_trainer_checkpoint_roundtrip_and_optional_losses(ngp, tmp_path):
     model.differentiable_normals = False
     with pytest.raises(RuntimeError, match="differentiable_normals"):
         tr3.step(o, d, gt)
+
+
+# ---------------------------------------------------------------------------- O1: fused sampled occupancy update
+def _grid_model(ngp, seed=3):
+    model = _make_model(ngp)
+    G = model.grid_size
+    model.register_buffer("density_grid", torch.zeros(model.cascades, G ** 3, device=DEV))
+    c = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=DEV)] * 3, indexing="ij"), -1)
+    model.register_buffer("grid_coords", c.reshape(-1, 3).contiguous())
+    model.grid_rng = torch.Generator(device=DEV).manual_seed(seed)
+    return model
+
+
+def test_grid_sample_cells_distribution_and_points(ngp):
+    """ngp_grid_sample_cells (networks.py:308-333 + 388-395): M uniform cells + M uniformly drawn occupied cells,
+    bucket-ordered, each with a point inside its cell; deterministic in the seed; no occupied cell -> the uniform
+    half only (here: repeated exactly)."""
+    from ngp_amd._lib import call, call_host
+    G, M, s = 128, 128 ** 3 // 4, 0.5
+    g3 = G ** 3
+    coords = np.stack(np.meshgrid(*[np.arange(G, dtype=np.int32)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    ctr = (coords.astype(np.float32) + 0.5) / G - 0.5
+    occ_xyz = (ctr ** 2).sum(-1) < 0.2 ** 2                         # a ball: ~3.4 % of the cells
+    grid = np.zeros(g3, np.float32)
+    grid[oracle.morton3D(coords)] = np.where(occ_xyz, 9.0, 0.3).astype(np.float32)
+    n_occ = int(occ_xyz.sum())
+    work = torch.empty(call_host("grid_sample_workspace", G, M), dtype=torch.int32, device=DEV)
+
+    def sample(grid_np, thr, seed):
+        idx = torch.empty(2 * M, dtype=torch.int32, device=DEV)
+        xyz = torch.empty(2 * M, 3, dtype=torch.float32, device=DEV)
+        call("grid_sample_cells", T(grid_np), G, float(thr), M, seed, float(s), work, idx, xyz)
+        torch.cuda.synchronize()
+        return N(idx).astype(np.int64), N(xyz)
+
+    idx, xyz = sample(grid, 5.0, 1234)
+    assert idx.min() >= 0 and idx.max() < g3
+    assert (np.diff(idx) >= 0).all()                                 # G = 128: the 8 + 13 sort bits are the whole key
+    is_occ = grid[idx] > 5.0
+    expect = 0.5 + 0.5 * n_occ / g3                                  # all of the second half + the uniform hits
+    assert abs(is_occ.mean() - expect) < 4e-3, (is_occ.mean(), expect)
+    # the uniform half covers the volume evenly: octant counts of all samples outside the ball
+    cc = oracle.morton3D_invert(idx[~is_occ].astype(np.int32))
+    octant = (cc[:, 0] >= 64) * 4 + (cc[:, 1] >= 64) * 2 + (cc[:, 2] >= 64)
+    cnt = np.bincount(octant, minlength=8)
+    assert cnt.min() > 0.97 * cnt.mean() and cnt.max() < 1.03 * cnt.mean(), cnt
+    # occupied draws are uniform over the occupied cells: per-cell counts are Poisson(M / n_occ) (+ the uniform hits)
+    hits = np.bincount(idx[is_occ], minlength=g3)[grid > 5.0]
+    mean_hits = M / n_occ + M / g3
+    assert abs(hits.mean() - mean_hits) < 0.02 * mean_hits, (hits.mean(), mean_hits)
+    assert 0.9 * mean_hits < hits.var() < 1.1 * mean_hits, (hits.var(), mean_hits)
+    assert (hits == 0).mean() < 5 * np.exp(-mean_hits) + 1e-4 and hits.max() < 5 * mean_hits
+    # every point lies inside its cell: centre (c/(G-1)*2-1)*(s-s/G), half-width s/G (networks.py:391-395)
+    c3 = oracle.morton3D_invert(idx.astype(np.int32)).astype(np.float32)
+    centre = (c3 / (G - 1) * 2 - 1) * (s - s / G)
+    assert np.abs(xyz - centre).max() <= s / G * (1 + 1e-5)
+    assert np.abs(xyz - centre).mean() > 0.4 * s / G                 # jittered, not the centres
+    # same seed -> same samples (as a multiset of rows; the order inside a bucket is free), other seed -> other samples
+    idx2, xyz2 = sample(grid, 5.0, 1234)
+    key = lambda i, x: np.lexsort((x[:, 2], x[:, 1], x[:, 0], i))
+    o1, o2 = key(idx, xyz), key(idx2, xyz2)
+    assert np.array_equal(idx[o1], idx2[o2]) and np.array_equal(xyz[o1], xyz2[o2])
+    idx3, _ = sample(grid, 5.0, 99)
+    assert not np.array_equal(np.sort(idx), np.sort(idx3))
+    # nothing occupied: the second half repeats the first exactly
+    idx0, xyz0 = sample(grid, 100.0, 7)
+    o = key(idx0, xyz0)
+    assert np.array_equal(idx0[o][0::2], idx0[o][1::2]) and np.array_equal(xyz0[o][0::2], xyz0[o][1::2])
+
+
+def test_fused_sampled_grid_update_matches_torch_formulas(ngp):
+    """NGP.update_density_grid(warmup=False) on the fused kernels against the reference's formulas in torch ops
+    (networks.py:396-408) applied to the very same samples: density() of the points, last-write (here: max) into
+    the temporary grid, EMA with decay keeping negative cells, threshold = min(mean of positives, thr), packbits."""
+    from ngp_amd._lib import call, call_host
+    model = _grid_model(ngp)
+    with torch.no_grad():
+        model.xyz_net[2].bias.fill_(1.5)
+    thr0 = 0.01 * 1024 / 3 ** 0.5
+    model.update_density_grid(thr0, warmup=True)
+    with torch.no_grad():
+        model.density_grid[0, ::37] = -1.0                           # invisible cells stay as they are
+    G, M = model.grid_size, model.grid_size ** 3 // 4
+    for upd in range(2):
+        before = model.density_grid.clone()
+        # the samples the model is about to draw (same seed rule as NGP._update_density_grid_sampled)
+        if upd == 0:
+            seed0 = int(model.grid_rng.initial_seed()) & 0x7FFFFFFFFFFF
+        seed = seed0 + 1000003 * upd
+        work = torch.empty(call_host("grid_sample_workspace", G, M), dtype=torch.int32, device=DEV)
+        idx = torch.empty(2 * M, dtype=torch.int32, device=DEV)
+        xyz = torch.empty(2 * M, 3, dtype=torch.float32, device=DEV)
+        call("grid_sample_cells", before[0], G, float(thr0), M, seed, float(model.scale), work, idx, xyz)
+        with torch.no_grad():
+            sig = model.density(xyz)
+        tmp = torch.zeros_like(before[0]).scatter_reduce(0, idx.long(), sig, "amax", include_self=True)
+        want = torch.where(before[0] < 0, before[0], torch.maximum(before[0] * 0.95, tmp))
+        model.update_density_grid(thr0, warmup=False)
+        torch.cuda.synchronize()
+        assert torch.equal(model.density_grid[0], want)
+        pos = want[want > 0]
+        thr = min(float(pos.double().mean()), thr0)
+        bits = oracle.packbits(N(want), np.float32(thr))
+        mine = N(model.density_bitfield)
+        near = np.abs(N(want) - thr) < 1e-5 * thr                    # cells within rounding of the threshold
+        diff = np.unpackbits(mine ^ bits, bitorder="little").astype(bool)
+        assert not (diff & ~near).any(), int((diff & ~near).sum())
+        assert (N(want) < 0).sum() > 1000 and np.array_equal(N(model.density_grid[0])[N(want) < 0], N(want)[N(want) < 0])
+    # the torch-op route (NGP_GRID_UPDATE_TORCH=1) and the fused one agree on what an update does to the statistics
+    frac_fused = float((model.density_grid > min(float(model.density_grid[model.density_grid > 0].mean()), thr0)).float().mean())
+    assert 0.0 < frac_fused < 1.0
