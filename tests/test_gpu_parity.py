@@ -404,6 +404,13 @@ def test_grid_bwd_param_ray_ordered(ngp, log2T):
     out2 = torch.zeros(n_params, device=DEV)
     call("grid_bwd_param", gd, T(x), T(wide), L * Fd + 24, n, out2)
     close(N(out2), ref, 1e-4, 2e-5 * scale)
+    # per-sample row scale (the density head's d_sigma[s] * d(sigma)/d(features)[s]), incl. zero rows
+    rs = g.normal(size=n).astype(np.float32)
+    rs[g.random(n) < 0.15] = 0.0
+    ref_s = oracle.grid_bwd_param(desc, x, dy * rs[:, None], n_params)
+    out3 = torch.zeros(n_params, device=DEV)
+    call("grid_bwd_param_scaled", gd, T(x), T(dy), L * Fd, T(rs), n, out3)
+    close(N(out3), ref_s, 1e-4, 2e-5 * np.abs(ref_s).max())
 
 
 def test_grid_double_backward(ngp):

@@ -58,9 +58,14 @@ orig_call = _lib.call
 
 
 def spy(name, *args):
-    if name == "grid_bwd_param" and captured.get("on"):
+    if name in ("grid_bwd_param", "grid_bwd_param_scaled") and captured.get("on"):
+        if name == "grid_bwd_param_scaled":
+            desc, x, dy, lddy, rs, n, buf = args
+        else:
+            (desc, x, dy, lddy, n, buf), rs = args, None
+        cap = (desc, x, dy, lddy, rs, n, buf)
         captured.setdefault("launches", []).append(tuple(a.clone() if isinstance(a, torch.Tensor) and a.numel() < 2e8 else a
-                                                         for a in args))
+                                                         for a in cap))
     return orig_call(name, *args)
 
 
@@ -74,13 +79,13 @@ for i in range(steps):
     loss, res = tr.step(o, d, gt)
 torch.cuda.synchronize()
 print("samples/ray", int(res["total_samples"]) / 8192, "loss", float(loss))
-for desc, x, dy, lddy, n, buf in captured["launches"]:
+for desc, x, dy, lddy, rs, n, buf in captured["launches"]:
     tbl = torch.zeros(desc.offsets[desc.n_levels] * desc.n_features, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
-        orig_call("grid_bwd_param", desc, x, dy, lddy, n, tbl)
+        orig_call("grid_bwd_param_scaled", desc, x, dy, lddy, rs, n, tbl)
     e1.record()
     torch.cuda.synchronize()
     print(f"rows={desc.offsets[desc.n_levels]} n={n}: {e0.elapsed_time(e1) / reps:.3f} ms per launch")
