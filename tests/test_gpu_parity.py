@@ -1291,6 +1291,13 @@ def test_render_matches_reference_render_golden(ngp, golden, monkeypatch):
             assert (N(tst["semantic"])[hit] == g["test_semantic"][hit]).mean() > 0.97
 
 
+# Whole-step gradient bars, as max |mine - ref| / max |ref| per tensor.  Measured on MI355X (round 2): G8 <= 5.5e-5
+# (rgb_net; every other tensor <= 7.5e-6), G10 <= 3.5e-6 — fp32 summation order over ~3,000 samples (MFMA tiles,
+# atomics, parallel scans vs the CPU fixture's sequential sums) and __expf in the compositor; the bars leave a
+# factor ~5 (round 1 had 3e-3 / 5e-3 without having measured them).
+G8_BAR, G10_BAR = 3e-4, 5e-5
+
+
 def test_training_step_matches_reference_golden(ngp, golden, monkeypatch):
     """One whole training step against the G8 fixture — the reference's OWN render() -> NeRFLoss
     (losses.py) -> sum of term means -> backward through its autograd Functions -> clip_grad_norm_(50)
@@ -1335,11 +1342,13 @@ def test_training_step_matches_reference_golden(ngp, golden, monkeypatch):
         if np.abs(ref).max() == 0:                       # headers: the reference back-propagates exact zeros
             assert not mine.any(), k
         else:
-            assert rel(mine, ref) < 3e-3, (k, rel(mine, ref))
+            print(f"[G8] grad {k}: max-normalised error {rel(mine, ref):.2e}")
+            assert rel(mine, ref) < G8_BAR, (k, rel(mine, ref))
     for k in tables:
         idx = g["grad_idx_" + k]
         mine = N(named[k].grad)
-        assert rel(mine[idx], g["grad_val_" + k]) < 3e-3, k
+        print(f"[G8] grad {k}: max-normalised error {rel(mine[idx], g['grad_val_' + k]):.2e}")
+        assert rel(mine[idx], g["grad_val_" + k]) < G8_BAR, k
         assert abs(np.sqrt((mine.astype(np.float64) ** 2).sum()) - float(g["grad_l2_" + k])) < 3e-3 * float(g["grad_l2_" + k])
         assert abs(np.abs(mine).sum(dtype=np.float64) - float(g["grad_l1_" + k])) < 3e-3 * float(g["grad_l1_" + k])
     mine_grads = {k: N(named[k].grad).copy() for k in tables}
@@ -1444,10 +1453,12 @@ def test_normal_ref_step_matches_reference_golden(ngp, golden, monkeypatch):
         if np.abs(ref).max() == 0:
             assert not mine.any(), k
         else:
-            assert rel(mine, ref) < 5e-3, (k, rel(mine, ref))
+            print(f"[G10] grad {k}: max-normalised error {rel(mine, ref):.2e}")
+            assert rel(mine, ref) < G10_BAR, (k, rel(mine, ref))
     for k in ("xyz_encoder.params", "rgb_encoder.params"):
         mine = N(named[k].grad)
-        assert rel(mine[g["grad_idx_" + k]], g["grad_val_" + k]) < 5e-3, k
+        print(f"[G10] grad {k}: max-normalised error {rel(mine[g['grad_idx_' + k]], g['grad_val_' + k]):.2e}")
+        assert rel(mine[g["grad_idx_" + k]], g["grad_val_" + k]) < G10_BAR, k
         l2 = float(g["grad_l2_" + k])
         assert abs(np.sqrt((mine.astype(np.float64) ** 2).sum()) - l2) < 5e-3 * l2, k
 
