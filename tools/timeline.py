@@ -25,7 +25,11 @@ def short(name):
     return s[:58]
 
 
-STEP_MARK = "clip_coef_kernel"
+STEP_MARKS = ("clip_coef_kernel", "clip_decide_kernel")   # one of them per optimizer step (exact norm / norm bound)
+
+
+def is_mark(name):
+    return any(m in name for m in STEP_MARKS)
 
 
 def main(path, back=3, with_update=False):
@@ -33,7 +37,7 @@ def main(path, back=3, with_update=False):
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
     rows.sort()
-    adam = [i for i, r in enumerate(rows) if STEP_MARK in r[2]]
+    adam = [i for i, r in enumerate(rows) if is_mark(r[2])]
     if len(adam) < back + 2:
         raise SystemExit("not enough steps in the trace")
     if with_update:
@@ -60,7 +64,7 @@ def region(path, k, skip=0):
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if STEP_MARK in r[2]]
+    marks = [i for i, r in enumerate(rows) if is_mark(r[2])]
     # the timed region ends with the optimizer of its last step: take the K steps before the last mark
     lo, hi = marks[-k - 1 - skip], marks[-1 - skip]
     sel = rows[lo:hi]
