@@ -92,7 +92,7 @@ def _side_stream(dev):
     key = torch.device(dev).index
     st = _SIDE.get(key)
     if st is None:
-        st = _SIDE[key] = torch.cuda.Stream(device=dev)
+        st = _SIDE[key] = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("NGP_SIDE_PRIO", "0")))
     return st
 
 

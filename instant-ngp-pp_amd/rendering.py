@@ -60,7 +60,7 @@ class MarchAhead:
     was marched with (the trainer does not march across a density-grid update)."""
 
     def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)
+        self.stream = torch.cuda.Stream(device=device, priority=int(_os.environ.get("NGP_MARCH_PRIO", "0")))
         self.count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.pending = None
 

@@ -163,7 +163,9 @@ class NGPTrainer:
         # NGP_SERIAL_OPT=1 (A/B): clip + Adam on the caller's stream instead of the optimizer stream
         serial = os.environ.get("NGP_SERIAL_OPT", "0") == "1"
         self._opt_stream = (torch.cuda.current_stream(self.flat_param.device) if serial
-                            else torch.cuda.Stream(device=self.flat_param.device)) if self.flat_param.is_cuda else None
+                            else torch.cuda.Stream(device=self.flat_param.device,
+                                                   priority=int(os.environ.get("NGP_OPT_PRIO", "0")))
+                            ) if self.flat_param.is_cuda else None
         self._march_ahead = MarchAhead(self.flat_param.device) if self.flat_param.is_cuda else None
 
     # ------------------------------------------------------------------ flat parameter store
