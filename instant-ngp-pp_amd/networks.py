@@ -369,7 +369,15 @@ class _FieldFn(Function):
                 cb = getattr(xe, "on_grad_ready", None)
                 if cb is not None:
                     cb()
-            on_side(density_scatter)
+            # Data parallel: the colour table's gradient (77 % of the bytes) goes into its reduce-scatter the moment
+            # its scatter is enqueued, so there the colour scatter leads on the side stream and the density scatter
+            # follows it — the collective then runs under the density scatter and the weight products.
+            density_later = bool(getattr(re, "grad_ready_is_collective", False)) and d_rgb is not None and need[9]
+            if not density_later:
+                on_side(density_scatter)
+                density_scatter = None
+        else:
+            density_scatter = None
 
         # ---- colour branch (rgb_net + the two heads): data gradients w.r.t. [grid features | appearance code] first
         dfeat_rgb = None
@@ -410,6 +418,8 @@ class _FieldFn(Function):
                 on_side(colour_scatter)
             else:
                 colour_scatter()
+        if density_scatter is not None:
+            on_side(density_scatter)
         if dfeat_rgb is not None:
             if E and need[3]:
                 g_emb = dfeat_rgb[:, 128:]

@@ -231,6 +231,7 @@ class NGPTrainer:
         self.hooked0 = bool(hasattr(self.model, "rgb_encoder") and self.sharded and b0)
         if self.hooked0:
             self.model.rgb_encoder.on_grad_ready = lambda: self.buckets.reduce_scatter_bucket(0, self.grad_shard[0])
+            self.model.rgb_encoder.grad_ready_is_collective = True   # the field's backward then scatters colour first
         elif (hasattr(self.model, "rgb_encoder") and b0 and dev.type == "cuda" and not self.sharded
               and os.environ.get("NGP_NO_EARLY_NORM", "0") != "1"):
             # one GPU: the colour table's share of the gradient norm (77 % of the entries) is summed
