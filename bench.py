@@ -258,6 +258,34 @@ def main():
     run(post_steps, args.warmup + args.steps, False)
     torch.cuda.synchronize()
     comm_trace, trainer.buckets.trace = trainer.buckets.trace, None
+    # SOLO rates: one more untimed step with the arguments of the scatter / MLP launches captured, then every one of
+    # them replayed alone on an idle device (3 repetitions).  In the step these kernels share the memory system with
+    # whatever runs on the other streams (the two scatters run beside the MLP weight products by design), so their
+    # in-step durations say how the schedule shares the device, the solo ones what the kernel itself does.
+    solo_keys = SCATTER_CALLS + ("mlp_bwd_input", "mlp_bwd_weight", "mlp2_fwd", "grid_fwd", "grid_bwd_input")
+    solo = {}
+    if world == 1:
+        extra = 0
+        if trainer.global_step % trainer.update_interval == 0:   # not a step that starts with an occupancy update
+            run(1, args.warmup + args.steps + post_steps, False)
+            extra = 1
+        _lib.CAPTURE = {k: [] for k in solo_keys}
+        run(1, args.warmup + args.steps + post_steps + extra, False)
+        trainer.wait()
+        torch.cuda.synchronize()
+        cap, _lib.CAPTURE = _lib.CAPTURE, None
+        for name, calls in cap.items():
+            for a in calls:
+                _lib.call(name, *a)               # once untimed (code / TLB warm)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(3):
+                    _lib.call(name, *a)
+                e1.record()
+                torch.cuda.synchronize()
+                key = "grid_bwd_param" if name in SCATTER_CALLS else name
+                solo.setdefault(key, []).append((e0.elapsed_time(e1) / 3, tuple(x for x in a if isinstance(x, int))))
     # multi-GPU readiness: what every rank sent through the backend per step, and behind which HIP stream
     main_stream = torch.cuda.current_stream().cuda_stream
     per_step = {}
@@ -330,6 +358,20 @@ def main():
                               "GBps": tot_b / (sum(ms) * 1e-3) / 1e9, "frac_of_hbm_peak": tot_b / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
             else:
                 kern[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms)}
+        for name, runs in solo.items():
+            if name not in kern or not runs:
+                continue
+            ms = [m for m, _ in runs]
+            kern[name]["solo_avg_ms"] = sum(ms) / len(ms)
+            if name.startswith("grid"):
+                ns = [a[N_ARG[name]] for _, a in runs]
+                kern[name]["solo_GBps"] = BYTES_PER_SAMPLE[name] * sum(ns) / (sum(ms) * 1e-3) / 1e9
+            else:
+                sel = [(m, 2.0 * a[5] * a[6] * a[7]) for m, a in runs if min(a[6], a[7]) >= 32]
+                if sel:
+                    kern[name]["solo_TFLOPs"] = sum(f for _, f in sel) / (sum(m for m, _ in sel) * 1e-3) / 1e12
+                    kern[name]["solo_ms_mfma"] = sum(m for m, _ in sel)
+                    kern[name]["solo_flop_mfma"] = sum(f for _, f in sel)
         for name in kern:
             kern[name]["steps"] = steps_of(name)
             kern[name]["ms_per_step"] = kern[name]["total_ms"] / kern[name]["steps"]
@@ -373,6 +415,9 @@ def main():
                  "avg_launch_ms": k["avg_ms"], "ms_per_step": k["ms_per_step"], "launches": k["launches"],
                  "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
                  "formula": "achieved = sum over the timed region's launches of algorithmic bytes / sum of their HIP-event durations"}
+            if "solo_GBps" in k:
+                r["solo"] = {"achieved": k["solo_GBps"], "frac": k["solo_GBps"] / HBM_PEAK_GBS, "avg_launch_ms": k["solo_avg_ms"],
+                             "note": "the same launches (arguments captured from one more step) replayed alone on an idle device"}
             if name == "grid_bwd_param":
                 r["algorithmic_bytes_per_sample"] = BYTES_PER_SAMPLE[name]
                 req = pmc_all.get(name, {}).get("atomic_requests_per_sample")
@@ -400,7 +445,13 @@ def main():
             mlp = {"bound": "mfma", "achieved": fl / t_ms, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": fl / t_ms / MFMA_F32_PEAK_TFLOPS, "ms_per_step": t_ms / post_steps,
                    "note": "all MFMA-tiled linear_* / mlp2_fwd / mlp_bwd_* launches of the step, fp32 operands, "
-                           "v_mfma_f32_32x32x2_f32; HIP events over the untimed steps right after the timed region"}
+                           "v_mfma_f32_32x32x2_f32; HIP events over the untimed steps right after the timed region "
+                           "(in-step: the weight products run beside the two table scatters on purpose)"}
+            sfl = sum(k.get("solo_flop_mfma", 0.0) for k in lin)
+            sms = sum(k.get("solo_ms_mfma", 0.0) for k in lin)
+            if sms > 0:
+                mlp["solo"] = {"achieved": sfl / (sms * 1e-3) / 1e12, "frac": sfl / (sms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                               "ms_per_step": sms, "note": "the same launches replayed alone on an idle device"}
         out = {
             "metric": "train rays/sec", "value": rays_total / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -106,11 +106,16 @@ def stream_ptr():
 # Optional per-entry-point device timing: {name: [(start_event, end_event, tag), ...]}.  bench.py sets
 # this to bracket the kernels of the timed region with HIP events on the launch stream.
 PROFILE = None
+# Optional capture of the argument tuples of chosen entry points ({name: [args, ...]}): bench.py replays them alone
+# after the timed region to report every kernel's solo rate beside its in-step rate.
+CAPTURE = None
 
 
 def call(name, *args):
     """Calls ngp_<name>(*args, current HIP stream).  Tensors are passed as device pointers."""
     lib = load()
+    if CAPTURE is not None and name in CAPTURE:
+        CAPTURE[name].append(args)
     prof = PROFILE
     if prof is not None and name in prof:
         e0 = torch.cuda.Event(enable_timing=True)
