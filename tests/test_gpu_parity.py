@@ -1977,3 +1977,138 @@ def test_fused_sampled_grid_update_matches_torch_formulas(ngp):
     # the torch-op route (NGP_GRID_UPDATE_TORCH=1) and the fused one agree on what an update does to the statistics
     frac_fused = float((model.density_grid > min(float(model.density_grid[model.density_grid > 0].mean()), thr0)).float().mean())
     assert 0.0 < frac_fused < 1.0
+
+
+# ---------------------------------------------------------------------------- full-size checks (BASELINE config 1)
+@pytest.fixture(scope="module")
+def full_batch(ngp):
+    """One batch of configs[1]: 8192 rays through the S-lego-proxy scene's analytic occupancy (128^3 grid, scale 0.5),
+    marched by the HIP marcher: ~0.4-0.5 M samples in ray order, as a training step sees them."""
+    from ngp_amd.synthetic import LegoProxy
+    from ngp_amd.custom_functions import RayAABBIntersector, RayMarcher
+    torch.manual_seed(20220806)
+    model = _grid_model(ngp, seed=20220806)
+    scene = LegoProxy(n_images=100, img_wh=(800, 800), device=DEV, seed=20220806)
+    with torch.no_grad():
+        model.density_grid.copy_(scene.occupancy_from_analytic(model))
+    ngp.vren.packbits(model.density_grid.view(-1), 0.5, model.density_bitfield)
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    img, pix = scene.sample_batch(8192, generator=gen)
+    o, d = scene.rays(img, pix)
+    _, hits_t, _ = RayAABBIntersector.apply(o, d, model.center, model.half_size, 1)
+    hits_t = hits_t.contiguous()
+    ngp._lib.call("clamp_near", hits_t, hits_t.shape[0], 1, 0.01)
+    with torch.no_grad():
+        rays_a, xyzs, dirs, deltas, ts, total = RayMarcher.apply(o, d, hits_t[:, 0], model.density_bitfield, model.cascades,
+                                                                 model.scale, 0.0, model.grid_size, 1024)
+    return dict(model=model, o=o, d=d, hits_t=hits_t[:, 0], rays_a=rays_a, xyzs=xyzs, dirs=dirs, deltas=deltas, ts=ts,
+                n=int(total))
+
+
+def test_full_size_marcher_invariants(ngp, full_batch):
+    """8192 rays, ~0.45 M samples: the segments tile [0, N) in ray order; inside a ray t increases by exactly the
+    previous delta or more; delta = dt(t) = sqrt(3)/1024 (exp_step_factor 0, raymarching.cu:11-13); every sample
+    lies in a cell whose bit is set (oracle's bit test on the same positions); x = o + t d, bit for bit."""
+    b = full_batch
+    ra, n = N(b["rays_a"]), b["n"]
+    assert 300_000 < n < 700_000
+    assert np.array_equal(ra[:, 0], np.arange(8192))
+    assert np.array_equal(ra[:, 1], np.concatenate([[0], np.cumsum(ra[:, 2])[:-1]])) and ra[:, 2].sum() == n
+    assert ra[:, 2].max() <= 1024
+    ts, deltas, xyz = N(b["ts"]), N(b["deltas"]), N(b["xyzs"])
+    assert np.all(deltas == np.float32(3 ** 0.5 / 1024))
+    ray_of = np.repeat(np.arange(8192), ra[:, 2])
+    same = ray_of[1:] == ray_of[:-1]
+    assert np.all(ts[1:][same] >= (ts[:-1] + deltas[:-1])[same])       # a step, or a jump over empty cells
+    o, d = N(b["o"]), N(b["d"])
+    want = (o[ray_of].astype(np.float32) + ts[:, None] * d[ray_of].astype(np.float32))
+    assert np.abs(xyz - want).max() <= 1e-6                             # same expression; fma contraction is off on both sides
+    t12 = N(b["hits_t"])[ray_of]
+    assert np.all(ts >= t12[:, 0]) and np.all(ts < t12[:, 1])
+    # occupancy of every sample's cell (mip 0: scale 0.5): n = clamp(0.5*(x/0.5+1)*128), bit idx = morton
+    G = 128
+    cell = np.clip((0.5 * (xyz / np.float32(0.5) + 1) * G).astype(np.int32), 0, G - 1)
+    idx = oracle.morton3D(cell)
+    bits = N(b["model"].density_bitfield)
+    assert np.all((bits[idx >> 3] >> (idx & 7)) & 1)
+
+
+@pytest.mark.parametrize("log2T", [19, 21])
+def test_full_size_grid_adjoint_and_oracle(ngp, full_batch, log2T):
+    """The scatter is the adjoint of the gather: <grid_fwd(table, x), dy> = <table, grid_bwd_param(x, dy)>, on the
+    full batch (both of the reference's tables), plus the whole scatter result against the CPU oracle and the
+    input gradient against the oracle on a strided subset."""
+    from ngp_amd._lib import call, call_host
+    b = full_batch
+    n = b["n"]
+    L, Fd, base, pls = 16, 8, 16, float(np.exp(np.log(2048 * 0.5 / 16) / 15))
+    gd = ngp._lib.GridDesc()
+    n_params = call_host("grid_layout", L, Fd, log2T, base, pls, gd)
+    g = rng(300 + log2T)
+    xn = ((b["xyzs"] + 0.5)).clamp(0, 1).contiguous()
+    table = T(g.uniform(-1, 1, n_params).astype(np.float32))
+    dy = torch.randn(n, L * Fd, device=DEV, generator=torch.Generator(device=DEV).manual_seed(log2T))
+    dy[torch.rand(n, device=DEV) < 0.19] = 0.0                          # samples behind the termination point
+    y = torch.empty(n, L * Fd, device=DEV)
+    call("grid_fwd", gd, table, xn, n, y, L * Fd)
+    dtable = torch.zeros(n_params, device=DEV)
+    call("grid_bwd_param", gd, xn, dy, L * Fd, n, dtable)
+    lhs = float((y.double() * dy.double()).sum())
+    rhs = float((table.double() * dtable.double()).sum())
+    scale = float((y.double() * dy.double()).abs().sum())
+    assert abs(lhs - rhs) < 2e-6 * scale, (lhs, rhs, scale)
+    desc, _ = oracle.grid_layout(L, Fd, log2T, base, pls)
+    ref = oracle.grid_bwd_param(desc, N(xn), N(dy), n_params)
+    close(N(dtable), ref, 2e-4, 2e-5 * np.abs(ref).max())
+    sub = slice(0, n, 37)
+    ref_y = oracle.grid_fwd(desc, N(table), N(xn)[sub])
+    close(N(y)[sub], ref_y, 1e-5, 1e-6)
+    dx = torch.empty(n, 3, device=DEV)
+    call("grid_bwd_input", gd, table, xn, dy, L * Fd, n, dx)
+    ref_dx = oracle.grid_bwd_input(desc, N(table), N(xn)[sub], N(dy)[sub])
+    close(N(dx)[sub], ref_dx, 2e-4, 3e-6 * np.abs(ref_dx).max())
+
+
+def test_full_size_compositing_matches_oracle(ngp, full_batch):
+    """composite_train_fw / bw, distortion loss and RefLoss on the full batch's own segments (0..1024 samples per
+    ray) against the CPU oracle; plus the identities sum(ws) = opacity and opacity = 1 - prod(1 - alpha) up to the
+    termination threshold."""
+    b = full_batch
+    n, ra = b["n"], b["rays_a"]
+    g = torch.Generator(device=DEV).manual_seed(5)
+    sig = torch.rand(n, device=DEV, generator=g) ** 3 * 400
+    sig[torch.rand(n, device=DEV, generator=g) < 0.5] = 0
+    rgbs, nrm = torch.rand(n, 3, device=DEV, generator=g), torch.randn(n, 3, device=DEV, generator=g)
+    sems = torch.rand(n, 7, device=DEV, generator=g)
+    outs = ngp.vren.composite_train_fw(sig, rgbs, nrm, sems, b["deltas"], b["ts"], ra, 1e-4, 7)
+    ref = oracle.composite_train_fw(N(sig), N(rgbs), N(nrm), N(sems), N(b["deltas"]), N(b["ts"]), N(ra), 1e-4, 7)
+    loose = borderline_rays(N(sig), N(b["deltas"]), N(ra), 1e-4)
+    assert loose.mean() < 0.01
+    keep = ~loose
+    for a, r in zip(outs[1:6], ref[1:6]):
+        close(N(a)[keep], r[keep], 2e-5, 2e-6)
+    ws = N(outs[6])
+    ray_of = np.repeat(np.arange(8192), N(ra)[:, 2])
+    ok = keep[ray_of]
+    close(ws[ok], ref[6][ok], 2e-5, 1e-7)
+    close(np.bincount(ray_of, weights=ws, minlength=8192)[keep], N(outs[1])[keep], 1e-5, 1e-6)
+    assert N(outs[1]).max() <= 1.0 + 1e-5
+    # backward on the same segments
+    up = [torch.randn_like(o) for o in outs[1:7]]
+    grads = ngp.vren.composite_train_bw(*up, sig, rgbs, nrm, outs[6], b["deltas"], b["ts"], ra, outs[1], outs[2], outs[3],
+                                        outs[4], 1e-4, 7)
+    rg = oracle.composite_train_bw(*[N(u) for u in up], N(sig), N(rgbs), N(nrm), ref[6], N(b["deltas"]), N(b["ts"]), N(ra),
+                                   ref[1], ref[2], ref[3], ref[4], 1e-4, 7)
+    for a, r in zip(grads, rg):
+        close(N(a)[ok], r[ok], 2e-4, 2e-5 * np.abs(r).max())
+    # distortion loss (losses.cu) and its gradient
+    loss, wi, wti = ngp.vren.distortion_loss_fw(outs[6], b["deltas"], b["ts"], ra)
+    rl, rwi, rwti = oracle.distortion_loss_fw(ws, N(b["deltas"]), N(b["ts"]), N(ra))
+    close(N(wi), rwi, 1e-5, 1e-7)
+    close(N(wti), rwti, 1e-5, 1e-6)
+    # the per-ray loss is a difference of two prefix-sum products of size ~ opacity^2 * t (up to ~2 here): fp32
+    # summation order shows at 1e-5 of THAT magnitude (measured 3.3e-5 absolute on rays of up to 1024 samples)
+    close(N(loss), rl, 1e-3, 1e-4)
+    dws = ngp.vren.distortion_loss_bw(torch.ones(8192, device=DEV), wi, wti, outs[6], b["deltas"], b["ts"], ra)
+    close(N(dws), oracle.distortion_loss_bw(np.ones(8192, np.float32), rwi, rwti, ws, N(b["deltas"]), N(b["ts"]), N(ra)),
+          1e-4, 1e-5)
