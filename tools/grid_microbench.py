@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Times the hash-grid kernels on tensors captured from a real training step (GPU only)."""
+"""Times the hash-grid kernels on tensors captured from a real training step (GPU only).
+The superseded scatter variants (MB_VARIANTS=slide,pair,merge,simple) exist only in the A/B build:
+    NGP_AB_VARIANTS=1 python -m instant-ngp-pp_amd.build && NGP_AB_VARIANTS=1 python tools/grid_microbench.py
+The library reads its variant switches once per process: run one variant per invocation (MB_VARIANTS=slide ...).
+(`line` = the product kernel; tools/scatter_replay.py times it on a steady-state batch and summarises PMC passes)."""
 import os
 import sys
 import time
@@ -65,10 +69,13 @@ for idx, args in enumerate(captured["grid_bwd_param"]):
     nz_rows = (dy.abs().sum(1) > 0).float().mean().item()
     nz_el = (dy != 0).float().mean().item()
     tbl = torch.zeros(desc.offsets[desc.n_levels] * desc.n_features, device=dev)
-    for variant in os.environ.get("MB_VARIANTS", "slide,pair,merge,simple").split(","):
+    for variant in os.environ.get("MB_VARIANTS", "line,slide,pair,merge,simple").split(","):
         os.environ.pop("NGP_GRID_BWD_SIMPLE", None)
         os.environ.pop("NGP_GRID_BWD_NOPAIR", None)
         os.environ.pop("NGP_GRID_BWD_NOSLIDE", None)
+        os.environ.pop("NGP_GRID_BWD_NOLINE", None)
+        if variant == "slide":
+            os.environ["NGP_GRID_BWD_NOLINE"] = "1"
         if variant == "pair":
             os.environ["NGP_GRID_BWD_NOSLIDE"] = "1"
         if variant == "simple":
