@@ -258,6 +258,7 @@ def main():
     run(post_steps, args.warmup + args.steps, False)
     torch.cuda.synchronize()
     comm_trace, trainer.buckets.trace = trainer.buckets.trace, None
+    prof, _lib.PROFILE = _lib.PROFILE, None      # the replays below are timed on their own
     # SOLO rates: one more untimed step with the arguments of the scatter / MLP launches captured, then every one of
     # them replayed alone on an idle device (3 repetitions).  In the step these kernels share the memory system with
     # whatever runs on the other streams (the two scatters run beside the MLP weight products by design), so their
@@ -306,7 +307,6 @@ def main():
               f"sharded optimizer {trainer.sharded}; per step: " +
               "; ".join(f"{c['op']} bucket {c['bucket']} {c['MB']} MB behind {c['enqueued_behind']}" for c in comm["per_step"]),
               file=sys.stderr, flush=True)
-    prof, _lib.PROFILE = _lib.PROFILE, None
     prof.update(prof_live)
     # the field calls the scaled entry point, other callers the plain one: one kernel, one entry in the tables
     prof["grid_bwd_param"] = [ev for k in SCATTER_CALLS for ev in prof.pop(k, [])]
