@@ -402,6 +402,25 @@ int ngp_sumsq(const float* x, int64_t n, float* out, void* stream);
  * extra_scale carries 1/world_size for summed (not yet averaged) data-parallel gradients. */
 int ngp_clip_coef(const float* sumsq, float max_norm, float extra_scale, float* coef, void* stream);
 
+/* Gradient clipping settled from an upper bound of the norm, without reading the 0.8 GB table gradients.
+ * A 2-layer MLP (hidden activation with |act'| <= 1: ReLU, Softplus) sends dfeat[s] = (act'(h) * (dz2[s] . W2)) . W1
+ * into its encoder, so ||dfeat[s]||_2 <= ||dz2[s]||_2 ||W2||_F ||W1||_F, and the encoder's scatter adds, per sample,
+ * a vector whose norm is at most ||dfeat[s]||_2 (trilinear weights: sum of squares <= 1).  Hence
+ *   ||table gradient||_2 <= ||W1||_F ||W2||_F * sum_s ||dz2[s]||_2 .
+ * ngp_row_norm_sum accumulates sum_s ||x[s, 0:cols]||_2 into *out (caller zeroes);
+ * ngp_clip_decide takes those sums for two tables (row_norm_sums[0], [1]), the two weight blocks of each MLP and the
+ * EXACT sum of squares of every other gradient, forms bound = sqrt(B0^2 + B1^2 + *sumsq_rest) * extra_scale and, when
+ * bound * 1.001 + 1e-6 < max_norm, writes *coef = extra_scale (the exact coefficient: nothing is clipped) and
+ * *need_exact = 0; otherwise *need_exact = 1 and the caller's ngp_sumsq_if / ngp_clip_coef_if launches (no-ops when the
+ * flag is 0) compute the exact norm and coefficient.  NaN / inf anywhere takes the exact route. */
+int ngp_row_norm_sum(const float* x, int64_t ldx, int64_t n, int cols, float* out, void* stream);
+int ngp_clip_decide(const float* row_norm_sums, const float* w1_a, int64_t n1_a, const float* w2_a, int64_t n2_a,
+                    const float* w1_b, int64_t n1_b, const float* w2_b, int64_t n2_b, const float* sumsq_rest,
+                    float max_norm, float extra_scale, float* coef, int32_t* need_exact, void* stream);
+int ngp_sumsq_if(const float* x, int64_t n, float* out, const int32_t* flag, void* stream);
+int ngp_clip_coef_if(const float* sumsq, float max_norm, float extra_scale, float* coef, const int32_t* flag,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

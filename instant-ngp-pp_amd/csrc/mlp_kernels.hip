@@ -1352,8 +1352,11 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
     }
 }
 
-__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out)
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out,
+                                                    const int32_t* __restrict__ flag)
 {
+    if (flag && *flag == 0) return;   // the clip decision did not need the exact norm
+
     __shared__ float part[4];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1380,8 +1383,11 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x,
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
-__global__ void __launch_bounds__(256) sumsq_scalar_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out)
+__global__ void __launch_bounds__(256) sumsq_scalar_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out,
+                                                           const int32_t* __restrict__ flag)
 {
+    if (flag && *flag == 0) return;
+
     __shared__ float part[4];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float a = 0.0f;
@@ -1398,6 +1404,72 @@ __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm
                                  float* __restrict__ coef)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float norm = sqrtf(*sumsq) * extra_scale;
+        float c = max_norm / (norm + 1e-6f);
+        if (c > 1.0f) c = 1.0f;
+        *coef = c * extra_scale;
+    }
+}
+
+// sum over rows of the Euclidean norm of the first `cols` entries (cols <= 16): one lane per row
+__global__ void __launch_bounds__(256) row_norm_sum_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int cols,
+                                                           float* __restrict__ out)
+{
+    __shared__ float part[4];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float a = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float q = 0.0f;
+        for (int c = 0; c < cols; c++) { const float v = x[i * ldx + c]; q = fmaf(v, v, q); }
+        a += sqrtf(q);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// clipping settled from an upper bound of the gradient norm (see ngp_clip_decide in the header)
+__global__ void __launch_bounds__(1024) clip_decide_kernel(const float* __restrict__ sums,
+                                                           const float* __restrict__ w1a, int64_t n1a,
+                                                           const float* __restrict__ w2a, int64_t n2a,
+                                                           const float* __restrict__ w1b, int64_t n1b,
+                                                           const float* __restrict__ w2b, int64_t n2b,
+                                                           const float* __restrict__ sumsq_rest, float max_norm,
+                                                           float extra_scale, float* __restrict__ coef,
+                                                           int32_t* __restrict__ need_exact)
+{
+    __shared__ float ws[4][16];
+    const float* ptr[4] = {w1a, w2a, w1b, w2b};
+    const int64_t cnt[4] = {n1a, n2a, n1b, n2b};
+    for (int k = 0; k < 4; k++) {
+        float q = 0.0f;
+        for (int64_t i = threadIdx.x; i < cnt[k]; i += 1024) q = fmaf(ptr[k][i], ptr[k][i], q);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        if ((threadIdx.x & 63) == 0) ws[k][threadIdx.x >> 6] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float f[4];
+        for (int k = 0; k < 4; k++) {
+            float t = 0.0f;
+            for (int w = 0; w < 16; w++) t += ws[k][w];
+            f[k] = sqrtf(t);
+        }
+        const float ba = f[0] * f[1] * sums[0], bb = f[2] * f[3] * sums[1];
+        const float bound = sqrtf(ba * ba + bb * bb + (sumsq_rest ? *sumsq_rest : 0.0f)) * extra_scale;
+        const bool safe = bound * 1.001f + 1e-6f < max_norm;     // false for NaN / inf
+        *need_exact = safe ? 0 : 1;
+        if (safe) *coef = extra_scale;
+    }
+}
+
+__global__ void clip_coef_if_kernel(const float* __restrict__ sumsq, float max_norm, float extra_scale,
+                                    float* __restrict__ coef, const int32_t* __restrict__ flag)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0 && *flag != 0) {
         const float norm = sqrtf(*sumsq) * extra_scale;
         float c = max_norm / (norm + 1e-6f);
         if (c > 1.0f) c = 1.0f;
@@ -1828,6 +1900,11 @@ int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
 
 int ngp_sumsq(const float* x, int64_t n, float* out, void* stream)
 {
+    return ngp_sumsq_if(x, n, out, nullptr, stream);
+}
+
+int ngp_sumsq_if(const float* x, int64_t n, float* out, const int32_t* flag, void* stream)
+{
     if (n < 0 || !out) return NGP_EINVAL;
     if (n == 0) return NGP_OK;
     if (!x) return NGP_EINVAL;
@@ -1835,11 +1912,11 @@ int ngp_sumsq(const float* x, int64_t n, float* out, void* stream)
         int64_t blocks = ((n >> 2) + 255) / 256;
         if (blocks < 1) blocks = 1;
         if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+        hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out, flag);
     } else {
         int64_t blocks = (n + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(sumsq_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+        hipLaunchKernelGGL(sumsq_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out, flag);
     }
     return ngp_check_launch();
 }
@@ -1851,6 +1928,38 @@ int ngp_clip_coef(const float* sumsq, float max_norm, float extra_scale, float* 
     return ngp_check_launch();
 }
 
-const char* ngp_version(void) { return "ngp_hip 0.1 gfx950"; }
+int ngp_row_norm_sum(const float* x, int64_t ldx, int64_t n, int cols, float* out, void* stream)
+{
+    if (n < 0 || cols < 1 || cols > 16 || ldx < cols || !out) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!x) return NGP_EINVAL;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(row_norm_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, n, cols, out);
+    return ngp_check_launch();
+}
+
+int ngp_clip_decide(const float* row_norm_sums, const float* w1_a, int64_t n1_a, const float* w2_a, int64_t n2_a,
+                    const float* w1_b, int64_t n1_b, const float* w2_b, int64_t n2_b, const float* sumsq_rest,
+                    float max_norm, float extra_scale, float* coef, int32_t* need_exact, void* stream)
+{
+    if (!row_norm_sums || !w1_a || !w2_a || !w1_b || !w2_b || n1_a < 1 || n2_a < 1 || n1_b < 1 || n2_b < 1 || !coef ||
+        !need_exact)
+        return NGP_EINVAL;
+    hipLaunchKernelGGL(clip_decide_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_norm_sums, w1_a, n1_a, w2_a,
+                       n2_a, w1_b, n1_b, w2_b, n2_b, sumsq_rest, max_norm, extra_scale, coef, need_exact);
+    return ngp_check_launch();
+}
+
+int ngp_clip_coef_if(const float* sumsq, float max_norm, float extra_scale, float* coef, const int32_t* flag,
+                     void* stream)
+{
+    if (!sumsq || !coef || !flag) return NGP_EINVAL;
+    hipLaunchKernelGGL(clip_coef_if_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq, max_norm, extra_scale,
+                       coef, flag);
+    return ngp_check_launch();
+}
+
+const char* ngp_version(void) { return "ngp_hip 0.2 gfx950"; }
 
 } // extern "C"

@@ -213,6 +213,19 @@ def _wait_params(model, rgb_table=True):
             model._rgb_params_ready = None
 
 
+def _bound_note(model, st, slot, n_out, n):
+    """The trainer's clip decision (ngp_clip_decide) bounds a table gradient's norm by ||W1||_F ||W2||_F sum_s ||dz2[s]||:
+    accumulate the sum for the MLP whose backward `st` is (slot 0: rgb_net, 1: density head)."""
+    acc = getattr(model, "_norm_bound_acc", None)
+    if acc is None:
+        return
+    if not st.fused:
+        model._norm_bound_ok = False
+        return
+    call("row_norm_sum", st.dz2, n_out, n, n_out, acc[slot:slot + 1])
+    model._norm_bound_hits = getattr(model, "_norm_bound_hits", 0) + 1
+
+
 class _FieldFn(Function):
     """The whole NGP field (networks.py:198-240) as one autograd node: explicit kernel launches on
     preallocated buffers, no concat (both encoders write straight into rgb_net's input matrix),
@@ -390,9 +403,11 @@ class _FieldFn(Function):
                           _RELU, 3, rgb_in, Kp, Kp, rgb_p, Kp, acc_rgbp, acc_rgbp[128 * Kp:], None, None)
             st.input_product(dfeat_rgb, W_cols, W_cols, 16, False)
             stages.append(st)
+            _bound_note(model, st, 0, 3, n)
         for d_o, p, a_h, out, n_out, slot in ((d_np, nrm_p, a_n, np_o, 3, "nrm"), (d_sem, sem_p, a_s, sem_o, C, "sem")):
             if d_o is None:
                 continue
+            model._norm_bound_ok = False    # a head adds to the colour features' gradient: outside the norm bound
             acc_p, g_p = grad_buffer(slot + "_p", p)
             first = dfeat_rgb is None
             if first:
@@ -435,6 +450,7 @@ class _FieldFn(Function):
             (acc_b1, g_b1), (acc_b2, g_b2) = grad_buffer("b1", (128,)), grad_buffer("b2", (1,))
             st = _Mlp2Bwd(d_sig.contiguous().view(n, 1), sig, 1, _SOFTPLUS, W2, a1, 128, _SOFTPLUS, 1,
                           feat, 128, 128, W1, 128, acc_W1, acc_W2, acc_b1, acc_b2)
+            _bound_note(model, st, 1, 1, n)
             if not reuse:
                 dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
                 st.input_product(dfeat, 128, 128, 0, False)

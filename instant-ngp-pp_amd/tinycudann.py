@@ -50,6 +50,7 @@ class _GridFwd(Function):
             if buf is not None:
                 # trainer-owned flat gradient: scatter-add straight into it (autograd sees None)
                 call("grid_bwd_param", enc.desc, x, dy, enc.n_output_dims, x.shape[0], buf)
+                enc._bound_valid = False   # a table-gradient contribution the trainer's norm bound does not cover
             else:
                 dparams = torch.zeros_like(params)
                 call("grid_bwd_param", enc.desc, x, dy, enc.n_output_dims, x.shape[0], dparams)
@@ -77,6 +78,8 @@ class _GridBwdInput(Function):
         ddx = ddx.contiguous()
         d_dy = torch.empty_like(dy) if ctx.needs_input_grad[0] else None
         d_params = torch.zeros_like(params) if ctx.needs_input_grad[2] else None
+        if d_params is not None:
+            enc._bound_valid = False       # the double backward adds to the table gradient outside the norm bound
         call("grid_bwd_bwd_input", enc.desc, params, x, dy, enc.n_output_dims, ddx, x.shape[0], d_params, d_dy)
         return d_dy, None, d_params, None
 

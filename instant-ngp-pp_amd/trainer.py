@@ -188,6 +188,10 @@ class NGPTrainer:
         self.flat_param = torch.zeros(total, dtype=_f32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=_f32, device=dev)
         self.scalars = torch.zeros(2, dtype=_f32, device=dev)  # [sum of squares, clip coefficient]
+        # clipping from a norm bound (ngp_clip_decide): sum_s ||dz2[s]|| of the two MLPs that feed the encoders, and the
+        # device flag "the bound did not settle it: compute the exact norm"
+        self.norm_acc = torch.zeros(2, dtype=_f32, device=dev)
+        self.need_exact = torch.zeros(1, dtype=torch.int32, device=dev)
         off = 0
         self.slices = {}
         for (n, p), sz in zip(named, sizes):
@@ -238,11 +242,18 @@ class NGPTrainer:
             # right behind its scatter, beside the density head's backward, instead of on the path
             # between the last scatter and Adam
             self.model.rgb_encoder.on_grad_ready = self._early_norm_share
+        # first element behind the two tables (the MLP parameters): their share of the norm is always summed exactly
+        self._mlp_lo = 0
+        if self.names[:2] == ["rgb_encoder.params", "xyz_encoder.params"] and len(self.names) > 2:
+            self._mlp_lo = self.slices[self.names[2]][0]
+        self.norm_bound = bool(self._mlp_lo and dev.type == "cuda" and not self.sharded and hasattr(self.model, "xyz_net")
+                               and os.environ.get("NGP_NO_NORM_BOUND", "0") != "1")
+        self._bound_step = False
         self._norm_share_armed = False   # step() arms it: exactly one backward per optimizer step
         self._norm_share_fired = 0
 
     def _early_norm_share(self):
-        if self._norm_share_armed:
+        if self._norm_share_armed and not self._bound_step:
             self._norm_share_fired += 1
             if self._norm_share_fired == 1:
                 b0 = self.buckets.bounds[1]
@@ -287,6 +298,14 @@ class NGPTrainer:
         results = render(model, rays_o, rays_d, exp_step_factor=self.exp_step_factor,
                          num_classes=self.num_classes, marched=marched, **self.render_kwargs)
         self._norm_share_armed, self._norm_share_fired = True, 0   # one backward follows, then the optimizer step
+        # clip_grad_norm_(50) from an upper bound of the norm (ngp_clip_decide) instead of the 0.8 GB sum-of-squares
+        # pass: only on the default recipe, where the fused field backward is the one writer of the table gradients
+        self._bound_step = bool(self.norm_bound and self.fused_loss and not loss_kwargs and not target
+                                and not getattr(model, "differentiable_normals", False))
+        model._norm_bound_acc = self.norm_acc if self._bound_step else None
+        model._norm_bound_hits, model._norm_bound_ok = 0, True
+        if self.norm_bound:
+            model.rgb_encoder._bound_valid = model.xyz_encoder._bound_valid = True
         if self.fused_loss and not loss_kwargs and not target:
             # same value and gradients as sum(term.mean()) over NeRFLoss's default terms; the
             # gradients are seeded directly (no loss node, no multiplications by 1)
@@ -326,14 +345,34 @@ class NGPTrainer:
             b0 = self.buckets.bounds[1] if len(self.buckets.bounds) > 2 else 0
             early = self._norm_share_armed and self._norm_share_fired == 1   # scalars[0] holds the colour table's share
             self._norm_share_armed, self._norm_share_fired = False, 0
+            m = self.model
+            bounded = bool(self._bound_step and getattr(m, "_norm_bound_hits", 0) == 2 and getattr(m, "_norm_bound_ok", False)
+                           and m.rgb_encoder._bound_valid and m.xyz_encoder._bound_valid)
+            self._bound_step = False
+            m._norm_bound_acc = None
             with torch.cuda.stream(side):
-                if early:
+                if bounded:
+                    lo = self._mlp_lo
+                    Kp = m.rgb_net.padded_in
+                    rgb_p, lin1, lin2 = m.rgb_net.params, m.xyz_net[0], m.xyz_net[2]
+                    call("sumsq", self.flat_grad[lo:n], n - lo, self.scalars[0:1])            # MLP gradients: exact
+                    call("clip_decide", self.norm_acc, rgb_p, 128 * Kp, rgb_p[128 * Kp:], rgb_p.numel() - 128 * Kp,
+                         lin1.weight, lin1.weight.numel(), lin2.weight, lin2.weight.numel(), self.scalars[0:1],
+                         float(self.clip_norm), 1.0, self.scalars[1:2], self.need_exact)
+                    # bound >= clip_norm (not seen in training): the exact norm after all, decided on the device
+                    call("sumsq_if", self.flat_grad[0:lo], lo, self.scalars[0:1], self.need_exact)
+                    call("clip_coef_if", self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2], self.need_exact)
+                    self.scalars[0:1].zero_()
+                    self.norm_acc.zero_()
+                elif early:
                     call("sumsq", self.flat_grad[b0:n], n - b0, self.scalars[0:1])
                 else:
                     self.scalars[0:1].zero_()
                     call("sumsq", self.flat_grad, n, self.scalars[0:1])
-                call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2])
-                self.scalars[0:1].zero_()   # ready for the next step's early share
+                if not bounded:
+                    call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2])
+                    self.scalars[0:1].zero_()   # ready for the next step's early share
+                    self.norm_acc.zero_()
                 # two pieces: [density table | MLPs] first — the next forward starts on them — then
                 # the colour table, which the field does not read before its colour branch
                 events = []

@@ -2112,3 +2112,93 @@ def test_full_size_compositing_matches_oracle(ngp, full_batch):
     dws = ngp.vren.distortion_loss_bw(torch.ones(8192, device=DEV), wi, wti, outs[6], b["deltas"], b["ts"], ra)
     close(N(dws), oracle.distortion_loss_bw(np.ones(8192, np.float32), rwi, rwti, ws, N(b["deltas"]), N(b["ts"]), N(ra)),
           1e-4, 1e-5)
+
+
+# ---------------------------------------------------------------------------- clipping from a norm bound
+def test_clip_decide_and_conditional_norm(ngp):
+    """ngp_row_norm_sum and ngp_clip_decide: bound = sqrt(sum_t (||W1_t||_F ||W2_t||_F S_t)^2 + exact rest) * scale; below
+    the threshold the coefficient is extra_scale and the exact-norm launches do nothing, otherwise they run."""
+    from ngp_amd._lib import call
+    g = rng(91)
+    rows = g.normal(size=(70001, 5)).astype(np.float32)
+    acc = torch.zeros(1, device=DEV)
+    call("row_norm_sum", T(rows), 5, rows.shape[0], 3, acc)
+    want = np.sqrt((rows[:, :3].astype(np.float64) ** 2).sum(1)).sum()
+    assert abs(float(acc) - want) < 1e-5 * want
+    x = T(g.normal(size=100003).astype(np.float32))
+    exact = float((N(x).astype(np.float64) ** 2).sum())
+    w1a, w2a = T(g.normal(size=1000).astype(np.float32)), T(g.normal(size=48).astype(np.float32))
+    w1b, w2b = T(g.normal(size=777).astype(np.float32)), T(g.normal(size=128).astype(np.float32))
+    fa = float(np.linalg.norm(N(w1a).astype(np.float64)) * np.linalg.norm(N(w2a).astype(np.float64)))
+    fb = float(np.linalg.norm(N(w1b).astype(np.float64)) * np.linalg.norm(N(w2b).astype(np.float64)))
+    for sa, sb, rest, max_norm, scale in ((3.0 / fa, 4.0 / fb, 144.0, 50.0, 1.0),       # bound 13: no clipping possible
+                                          (30.0 / fa, 40.0 / fb, 0.0, 50.0, 1.0),     # bound 50: not below 50
+                                          (30.0 / fa, 40.0 / fb, 0.0, 50.0, 0.5),     # averaged over 2 ranks: 25
+                                          (float("nan"), 1.0 / fb, 0.0, 50.0, 1.0),
+                                          (1e-3 / fa, 1e-3 / fb, 1e-8, 1e-4, 1.0)):
+        bound = np.sqrt((fa * sa) ** 2 + (fb * sb) ** 2 + rest) * scale
+        expect_exact = not (bound * 1.001 + 1e-6 < max_norm)
+        sums = T(np.array([rest], np.float32))
+        coef = torch.full((1,), -7.0, device=DEV)
+        flag = torch.full((1,), 5, dtype=torch.int32, device=DEV)
+        call("clip_decide", T(np.array([sa, sb], np.float32)), w1a, w1a.numel(), w2a, w2a.numel(), w1b, w1b.numel(), w2b,
+             w2b.numel(), sums, max_norm, scale, coef, flag)
+        call("sumsq_if", x, x.numel(), sums, flag)
+        call("clip_coef_if", sums, max_norm, scale, coef, flag)
+        torch.cuda.synchronize()
+        assert int(flag) == (1 if expect_exact else 0), (sa, sb, bound)
+        if expect_exact:
+            norm = np.sqrt(rest + exact) * scale
+            want_c = scale * min(1.0, max_norm / (norm + 1e-6))
+            assert abs(float(sums) - (rest + exact)) < 1e-4 * (rest + exact)
+        else:
+            want_c = scale
+            assert float(sums) == np.float32(rest)
+        assert abs(float(coef) - want_c) <= 1e-5 * want_c, (float(coef), want_c)
+
+
+def test_trainer_norm_bound_route_matches_exact_route(ngp):
+    """NGPTrainer settles clip_grad_norm_(50) from ||W1|| ||W2|| sum_s ||dz2[s]|| (an upper bound of each table
+    gradient's norm) — and the bound does hold against the exact norms; with a threshold the bound cannot clear, the
+    device falls back to the exact norm.  Both against a trainer with the bound switched off."""
+    from ngp_amd.trainer import NGPTrainer
+    o, d = make_rays(2048, scale=1.0, seed=93)
+    o, d = T(o), T(d)
+    gt = torch.rand(2048, 3, device=DEV)
+    seen = {}
+
+    def run(bound, clip):
+        model = _grid_model(ngp, seed=4)
+        model.update_density_grid(0.01 * 1024 / 3 ** 0.5, warmup=True)
+        tr = NGPTrainer(model, lr=1e-2, clip_norm=clip)
+        assert tr.norm_bound
+        tr.norm_bound = bound
+        tr.global_step = 1
+        if bound and clip == 50.0:      # look at the bound itself: table gradient norms vs the kernel's sums
+            orig = tr.optimizer_step
+
+            def spy():
+                torch.cuda.synchronize()
+                b0 = tr.buckets.bounds[1]
+                seen["norms"] = (float(tr.flat_grad[:b0].norm()), float(tr.flat_grad[b0:tr._mlp_lo].norm()))
+                seen["sums"] = N(tr.norm_acc).copy()
+                Kp = model.rgb_net.padded_in
+                p = model.rgb_net.params
+                seen["f"] = (float(p[:128 * Kp].norm() * p[128 * Kp:].norm()),
+                             float(model.xyz_net[0].weight.norm() * model.xyz_net[2].weight.norm()))
+                orig()
+            tr.optimizer_step = spy
+        tr.step(o, d, gt)
+        tr.wait()
+        torch.cuda.synchronize()
+        return float(tr.scalars[1]), int(tr.need_exact), tr.flat_param[tr._mlp_lo:].clone()
+
+    c_b, f_b, p_b = run(True, 50.0)
+    c_e, f_e, p_e = run(False, 50.0)
+    assert c_b == 1.0 and c_e == 1.0 and f_b == 0
+    assert torch.allclose(p_b, p_e, rtol=0, atol=2e-6)           # one Adam step of lr 1e-2 on the MLPs
+    for t in range(2):                                           # rgb table, density table
+        assert 0 < seen["norms"][t] <= seen["f"][t] * seen["sums"][t], (t, seen)
+    c_b, f_b, p_b = run(True, 1e-4)                              # the norm (~1e-2) is far above: clipping is active
+    c_e, f_e, p_e = run(False, 1e-4)
+    assert f_b == 1 and 0 < c_b < 0.5 and abs(c_b - c_e) < 2e-3 * c_e, (c_b, c_e)
