@@ -2196,7 +2196,10 @@ def test_trainer_norm_bound_route_matches_exact_route(ngp):
     c_b, f_b, p_b = run(True, 50.0)
     c_e, f_e, p_e = run(False, 50.0)
     assert c_b == 1.0 and c_e == 1.0 and f_b == 0
-    assert torch.allclose(p_b, p_e, rtol=0, atol=2e-6)           # one Adam step of lr 1e-2 on the MLPs
+    # one Adam step of lr 1e-2 on the MLPs in two separate runs: the same parameters, except where a gradient is of the
+    # size of eps = 1e-8 and the atomics' summation order decides how far lr * g / (|g| + eps) goes
+    diff = (p_b - p_e).abs()
+    assert float((diff <= 2e-6).float().mean()) > 0.99 and float(diff.max()) <= 2.01e-2
     for t in range(2):                                           # rgb table, density table
         assert 0 < seen["norms"][t] <= seen["f"][t] * seen["sums"][t], (t, seen)
     c_b, f_b, p_b = run(True, 1e-4)                              # the norm (~1e-2) is far above: clipping is active
