@@ -86,6 +86,16 @@ _STREAM_WGRAD = not (_os.environ.get("NGP_MLP_NO_STREAM") or _os.environ.get("NG
 # density head 0.54 -> 0.49 ms, rgb_net 0.60 -> 0.57 ms, 32-wide headers 0.22 -> 0.22 ms
 _FUSED_BWD_MAX_OUT = int(_os.environ.get("NGP_FUSED_BWD_MAX_OUT", "3"))
 _SIDE = {}
+_SIDE_FWD = {}
+_FWD_OVERLAP = _os.environ.get("NGP_NO_FWD_OVERLAP", "0") != "1"   # A/B: the colour branch of the forward on its own stream
+
+
+def _fwd_stream(dev):
+    key = torch.device(dev).index
+    st = _SIDE_FWD.get(key)
+    if st is None:
+        st = _SIDE_FWD[key] = torch.cuda.Stream(device=dev)
+    return st
 
 
 def _side_stream(dev):
@@ -250,68 +260,84 @@ class _FieldFn(Function):
         Kp = model.rgb_net.padded_in
         span = model._span()
         xn = (x - model.xyz_min).div_(span)
-
-        # density head
+        # every buffer comes from the caller's stream (the allocator then knows them as that stream's; the colour
+        # stream below only launches into them and is joined before anything is returned)
         feat = torch.empty(n, 128, dtype=_f32, device=dev)
-        call("grid_fwd", xe.desc, xyz_table, xn, n, feat, 128)
         a1 = torch.empty(n, 128, dtype=_f32, device=dev)
         sig = torch.empty(n, 1, dtype=_f32, device=dev)
+        dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
+        grads = torch.empty(n, 3, dtype=_f32, device=dev)   # d sigma / d xn (normalised coordinates)
+        rgb_in = torch.empty(n, Kp, dtype=_f32, device=dev)
+        a_r = torch.empty(n, 128, dtype=_f32, device=dev)
+        rgb_o = torch.empty(n, 3, dtype=_f32, device=dev)
+        a_n = torch.empty(n, 32, dtype=_f32, device=dev)
+        np_o = torch.empty(n, 3, dtype=_f32, device=dev)
+        a_s = torch.empty(n, 32, dtype=_f32, device=dev)
+        sem_o = torch.empty(n, C, dtype=_f32, device=dev)
+        dz2 = torch.empty(n, 1, dtype=_f32, device=dev) if _FUSED_BWD else None
+        dz1 = None if _FUSED_BWD else torch.empty(n, 128, dtype=_f32, device=dev)
+        feat_rgb = rgb_in[:, 16:144]
+        net = model.rgb_net
+
+        def colour_branch():
+            # [SH(16) | rgb grid features (128) | appearance code (E) | ones-padding] -> rgb_net, the two heads
+            call("sh_fwd_dirs", d, n, 4, rgb_in, Kp)
+            _wait_params(model)   # the colour table's Adam piece (the stream this runs on waits for it)
+            call("grid_fwd", re.desc, rgb_table, xn, n, rgb_in[:, 16:], Kp)
+            if E:
+                rgb_in[:, 144:K] = embed_a
+            if Kp > K:
+                rgb_in[:, K:] = 1.0
+            if _FUSED_FWD:
+                call("mlp2_fwd", rgb_in, Kp, rgb_p, Kp, None, _RELU, rgb_p[128 * Kp:], 128, None, net.output_activation,
+                     n, Kp, 128, 3, a_r, 128, rgb_o, 3)
+                call("mlp2_fwd", feat_rgb, Kp, nrm_p, 128, None, _RELU, nrm_p[32 * 128:], 32, None, _NONE,
+                     n, 128, 32, 3, a_n, 32, np_o, 3)
+            else:
+                call("linear_fwd", rgb_in, Kp, rgb_p, Kp, None, n, Kp, 128, _RELU, a_r, 128, None)
+                call("linear_fwd", a_r, 128, rgb_p[128 * Kp:], 128, None, n, 128, 3, net.output_activation, rgb_o, 3, None)
+                call("linear_fwd", feat_rgb, Kp, nrm_p, 128, None, n, 128, 32, _RELU, a_n, 32, None)
+                call("linear_fwd", a_n, 32, nrm_p[32 * 128:], 32, None, n, 32, 3, _NONE, np_o, 3, None)
+            if _FUSED_FWD and C <= 8:
+                call("mlp2_fwd", feat_rgb, Kp, sem_p, 128, None, _RELU, sem_p[32 * 128:], 32, None, _NONE,
+                     n, 128, 32, C, a_s, 32, sem_o, C)
+            else:
+                call("linear_fwd", feat_rgb, Kp, sem_p, 128, None, n, 128, 32, _RELU, a_s, 32, None)
+                call("linear_fwd", a_s, 32, sem_p[32 * 128:], 32, None, n, 32, C, _NONE, sem_o, C, None)
+
+        # The colour branch needs the positions and the colour table, nothing of the density path: it runs on a
+        # stream of its own from the moment the colour table's Adam piece is done, beside the rest of the density
+        # path and the analytic normals (which are stretched beyond that piece's end on one stream).
+        main = torch.cuda.current_stream()
+        side = _fwd_stream(dev) if (_FWD_OVERLAP and x.is_cuda) else None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                colour_branch()
+
+        # density head
+        call("grid_fwd", xe.desc, xyz_table, xn, n, feat, 128)
         if _FUSED_FWD:   # both layers in one launch: the 1-wide second layer rides in the MFMA epilogue
             call("mlp2_fwd", feat, 128, W1, 128, b1, _SOFTPLUS, W2, 128, b2, _SOFTPLUS, n, 128, 128, 1, a1, 128, sig, 1)
         else:
             call("linear_fwd", feat, 128, W1, 128, b1, n, 128, 128, _SOFTPLUS, a1, 128, None)
             call("linear_fwd", a1, 128, W2, 128, b2, n, 128, 1, _SOFTPLUS, sig, 1, None)
         # analytic d(sigma)/dx: back-substitute ones through the head, then the grid input gradient
-        dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
         if _FUSED_BWD:
-            dz2 = torch.empty(n, 1, dtype=_f32, device=dev)
             call("act_bwd", None, sig, n, _SOFTPLUS, dz2)          # upstream gradient = ones
             call("mlp_bwd_input", dz2, 1, W2, 128, a1, 128, _SOFTPLUS, W1, 128, n, 128, 128, 1, dfeat, 128, 0)
-            dz1 = None
         else:
-            dz1 = torch.empty(n, 128, dtype=_f32, device=dev)
             call("mlp_hidden_bwd", None, 0, sig, 1, _SOFTPLUS, W2, 128, a1, 128, _SOFTPLUS, n, 128, 1, None, 0, dz1, 128,
                  None, 0, None)
             call("linear_bwd_input", dz1, 128, W1, 128, n, 128, 128, dfeat, 128, 0)
-        grads = torch.empty(n, 3, dtype=_f32, device=dev)   # d sigma / d xn (normalised coordinates)
         call("grid_bwd_input", xe.desc, xyz_table, xn, dfeat, 128, n, grads)
-        del dz1
         # dfeat = d(sigma)/d(features) is kept: the density head has ONE output, so the gradient the backward
         # sends into the density encoder is d_sigma[s] * dfeat[s] — no second data-gradient product there
 
-        # colour branch: [SH(16) | rgb grid features (128) | appearance code (E) | ones-padding]
-        rgb_in = torch.empty(n, Kp, dtype=_f32, device=dev)
-        call("sh_fwd_dirs", d, n, 4, rgb_in, Kp)
-        _wait_params(model)   # the colour table's Adam piece ran under the density path above
-        call("grid_fwd", re.desc, rgb_table, xn, n, rgb_in[:, 16:], Kp)
-        if E:
-            rgb_in[:, 144:K] = embed_a
-        if Kp > K:
-            rgb_in[:, K:] = 1.0
-        feat_rgb = rgb_in[:, 16:144]
-        net = model.rgb_net
-        a_r = torch.empty(n, 128, dtype=_f32, device=dev)
-        rgb_o = torch.empty(n, 3, dtype=_f32, device=dev)
-        a_n = torch.empty(n, 32, dtype=_f32, device=dev)
-        np_o = torch.empty(n, 3, dtype=_f32, device=dev)
-        if _FUSED_FWD:
-            call("mlp2_fwd", rgb_in, Kp, rgb_p, Kp, None, _RELU, rgb_p[128 * Kp:], 128, None, net.output_activation,
-                 n, Kp, 128, 3, a_r, 128, rgb_o, 3)
-            call("mlp2_fwd", feat_rgb, Kp, nrm_p, 128, None, _RELU, nrm_p[32 * 128:], 32, None, _NONE,
-                 n, 128, 32, 3, a_n, 32, np_o, 3)
+        if side is not None:
+            main.wait_stream(side)
         else:
-            call("linear_fwd", rgb_in, Kp, rgb_p, Kp, None, n, Kp, 128, _RELU, a_r, 128, None)
-            call("linear_fwd", a_r, 128, rgb_p[128 * Kp:], 128, None, n, 128, 3, net.output_activation, rgb_o, 3, None)
-            call("linear_fwd", feat_rgb, Kp, nrm_p, 128, None, n, 128, 32, _RELU, a_n, 32, None)
-            call("linear_fwd", a_n, 32, nrm_p[32 * 128:], 32, None, n, 32, 3, _NONE, np_o, 3, None)
-        a_s = torch.empty(n, 32, dtype=_f32, device=dev)
-        sem_o = torch.empty(n, C, dtype=_f32, device=dev)
-        if _FUSED_FWD and C <= 8:
-            call("mlp2_fwd", feat_rgb, Kp, sem_p, 128, None, _RELU, sem_p[32 * 128:], 32, None, _NONE,
-                 n, 128, 32, C, a_s, 32, sem_o, C)
-        else:
-            call("linear_fwd", feat_rgb, Kp, sem_p, 128, None, n, 128, 32, _RELU, a_s, 32, None)
-            call("linear_fwd", a_s, 32, sem_p[32 * 128:], 32, None, n, 32, C, _NONE, sem_o, C, None)
+            colour_branch()
 
         ctx.model = model
         ctx.E, ctx.K, ctx.Kp, ctx.C = E, K, Kp, C
