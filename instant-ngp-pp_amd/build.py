@@ -30,7 +30,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 
 
 def _flags():
-    return COMMON + (["-DNGP_AB_VARIANTS"] if os.environ.get("NGP_AB_VARIANTS") else [])
+    # NGP_EXTRA_DEFS="-DNAME=VALUE ...": compile-time tuning constants for experiments (part of the build id)
+    extra = os.environ.get("NGP_EXTRA_DEFS", "").split()
+    return COMMON + (["-DNGP_AB_VARIANTS"] if os.environ.get("NGP_AB_VARIANTS") else []) + extra
 
 
 def _hipcc():

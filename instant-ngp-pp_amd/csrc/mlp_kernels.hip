@@ -872,7 +872,10 @@ __global__ void __launch_bounds__(512) mlp_stream_wgrad_kernel(GemmArgs p, int64
     // meet in LDS before the atomics — the 128 x n_in atomic adds per workgroup are a fixed cost (~55 us
     // per launch with two 4-wave workgroups per CU), one 8-wave workgroup per CU halves it at the same occupancy
     extern __shared__ float lds[];
-    constexpr int D = 8;
+#ifndef NGP_WGRAD_D
+#define NGP_WGRAD_D 8
+#endif
+    constexpr int D = NGP_WGRAD_D;     // steps (of two samples) the operand loads run ahead of the MFMAs
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, grp = threadIdx.x >> 8;
     const int li = lane & 31, lh = lane >> 5;
     const bool two = blockDim.x == 512;                  // launched with 4 waves instead: one group, no hand-over

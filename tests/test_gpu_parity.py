@@ -2205,3 +2205,72 @@ def test_trainer_norm_bound_route_matches_exact_route(ngp):
     c_b, f_b, p_b = run(True, 1e-4)                              # the norm (~1e-2) is far above: clipping is active
     c_e, f_e, p_e = run(False, 1e-4)
     assert f_b == 1 and 0 < c_b < 0.5 and abs(c_b - c_e) < 2e-3 * c_e, (c_b, c_e)
+
+
+# ---------------------------------------------------------------------------- tinycudann surface: the remaining otypes
+def test_tcnn_frequency_and_network_with_input_encoding(ngp):
+    """tinycudann.Encoding(Frequency) and NetworkWithInputEncoding (call site: models/networks_noCUDA.py:17-30,
+    Frequency n = 6 + a 5 x 128 ReLU MLP; also with a hash grid in front): one flat `params` vector (network first,
+    then encoding), forward and parameter / input gradients against a torch fp64 re-evaluation of the same layers."""
+    tcnn = ngp.tinycudann
+    g = rng(401)
+    x = T(g.random((777, 3)).astype(np.float32))
+    enc = tcnn.Encoding(3, {"otype": "Frequency", "n_frequencies": 6}).to(DEV)
+    y = enc(x)
+    assert y.shape == (777, 36) and enc.params.numel() == 0
+    k = 2.0 ** np.arange(6)
+    ang = N(x).astype(np.float64)[:, :, None] * k[None, None, :] * np.pi
+    close(N(y), np.stack([np.sin(ang), np.cos(ang)], -1).reshape(777, -1), 1e-4, 1e-4)
+
+    for enc_cfg in ({"otype": "Frequency", "n_frequencies": 6},
+                    {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 2, "log2_hashmap_size": 12,
+                     "base_resolution": 4, "per_level_scale": 1.5}):
+        net_cfg = {"otype": "CutlassMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128,
+                   "n_hidden_layers": 5 if enc_cfg["otype"] == "Frequency" else 2}
+        model = tcnn.NetworkWithInputEncoding(3, 3, enc_cfg, net_cfg).to(DEV)
+        assert [n for n, _ in model.named_parameters()] == ["params"]
+        if enc_cfg["otype"] == "HashGrid":
+            with torch.no_grad():
+                model.params[model._n_net:].uniform_(-0.5, 0.5)
+        xi = x.clone().requires_grad_(True)
+        out = model(xi)
+        assert out.shape == (777, 3)
+        up = T(g.normal(size=(777, 3)).astype(np.float32))
+        gp, gx = torch.autograd.grad(out, [model.params, xi], up)
+        # fp64 re-evaluation: the encoding through the package's own encoder module (checked elsewhere), the MLP in torch
+        net = model.network
+        shapes = net.layer_shapes
+        p64 = model.params.detach().double().clone().requires_grad_(True)
+        x64 = x.double().clone().requires_grad_(True)
+        if enc_cfg["otype"] == "Frequency":
+            kk = torch.tensor(k, device=DEV, dtype=torch.float64)
+            a = x64[:, :, None] * kk[None, None, :] * np.pi
+            h = torch.stack([torch.sin(a), torch.cos(a)], -1).reshape(777, -1)
+        else:
+            e2 = tcnn.Encoding(3, enc_cfg).to(DEV)
+            with torch.no_grad():
+                e2.params.copy_(model.params[model._n_net:])
+            h = e2(x).detach().double()
+        h = torch.cat([h, torch.ones(777, net.padded_in - h.shape[1], device=DEV, dtype=torch.float64)], 1)
+        off = 0
+        for li, (no, ni) in enumerate(shapes):
+            W = p64[off:off + no * ni].view(no, ni)
+            off += no * ni
+            h = h @ W.T
+            if li < len(shapes) - 1:
+                h = torch.relu(h)
+        ref = h[:, :3]
+        close(N(out), N(ref.detach()), 2e-4, 2e-5 * float(ref.detach().abs().max()))
+        if enc_cfg["otype"] == "Frequency":
+            rp, rx = torch.autograd.grad(ref, [p64, x64], up.double())
+            # per-sample input gradients: a hidden unit whose pre-activation is within fp32 rounding of 0 takes the other
+            # side of the ReLU kink in the fp64 re-evaluation — a handful of samples may differ, the rest must agree
+            okx = np.isclose(N(gx), N(rx), rtol=2e-3, atol=2e-4 * float(rx.abs().max()))
+            assert okx.mean() > 0.995, okx.mean()
+        else:
+            (rp,) = torch.autograd.grad(ref, [p64], up.double())
+        n_net = model._n_net
+        okp = np.isclose(N(gp)[:n_net], N(rp)[:n_net], rtol=1e-3, atol=1e-4 * float(rp[:n_net].abs().max()))
+        assert okp.mean() > 0.999, okp.mean()
+        if enc_cfg["otype"] == "HashGrid":
+            assert gp[n_net:].abs().sum() > 0          # the table receives its share through the flat vector
