@@ -205,3 +205,47 @@ def test_grad_buckets_allreduce_gloo_world2():
         p.join(60)
     assert all(ok for _, ok, _ in res)
     assert res[0][2] != res[1][2]  # ranks really drew different data
+
+
+def test_empty_and_negative_batches_through_the_c_abi(ngp):
+    """include/ngp_hip.h: "empty batches (n == 0) are valid and return NGP_OK before any pointer is looked at", and a
+    negative size is NGP_EINVAL — for every entry point that takes a batch size.  Runs without a GPU: neither case may
+    reach a launch (all data pointers are NULL here)."""
+    import ctypes as C
+    _lib = ngp._lib
+    lib = _lib.load()
+    size_args = {"n", "n_rays", "n_alive", "count", "n_seg", "n_bytes"}
+    desc = _lib.GridDesc()
+    assert _lib.call_host("grid_layout", 16, 8, 19, 16, 1.3195079, desc) > 0
+    small = {"degree": 4, "max_hits": 1, "n_voxels": 1, "n_spheres": 1, "cascades": 1, "n_samples": 1, "classes": 1, "width": 1,
+             "cols": 1, "grid_size": 128, "max_samples": 1024, "n_in": 16, "n_out": 1, "H": 32, "step": 1}
+    # entry points whose empty call needs more than NULLs (an output scalar, a counter) are exercised on the GPU instead
+    needs_outputs = {"ngp_density_grid_ema_threshold", "ngp_raymarching_train", "ngp_nerf_loss", "ngp_sumsq", "ngp_sumsq_if",
+                     "ngp_row_norm_sum"}
+    checked = 0
+    for name, (_, args) in _lib.PROTOS.items():
+        names = [a for _, a in args]
+        if not (set(names) & size_args) or names[-1] != "stream":
+            continue
+
+        def build(size):
+            vals = []
+            for t, a in args:
+                if a in size_args:
+                    vals.append(size)
+                elif a == "desc":
+                    vals.append(C.addressof(desc))
+                elif t is C.c_void_p:
+                    vals.append(None)
+                elif t in (C.c_float, C.c_double):
+                    vals.append(1.0)
+                elif a.startswith("ld"):
+                    vals.append(128)
+                else:
+                    vals.append(small.get(a, 0))
+            return vals
+        assert getattr(lib, name)(*build(-1)) == -22, name
+        if name not in needs_outputs:
+            assert getattr(lib, name)(*build(0)) == 0, name
+        checked += 1
+    assert checked >= 40
