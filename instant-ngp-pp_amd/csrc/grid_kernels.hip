@@ -422,6 +422,8 @@ __global__ void __launch_bounds__(256) grid_bwd_param_slide_kernel(GridMeta meta
     }
 }
 
+// Superseded by grid_bwd_param_tag_kernel below (round 2): compiled only into the A/B build.
+#ifdef NGP_AB_VARIANTS
 // Line-aligned sliding window (F = 8: a table row is 32 bytes, a 64-byte atomic request covers the two
 // rows (2k, 2k+1) of a level).  Memory-side float atomics are limited by REQUESTS, one per 64-byte line a
 // wave-instruction touches (tools/atomic_shapes.hip: 20 G requests/s whether a request carries 4 or 64
@@ -433,7 +435,7 @@ __global__ void __launch_bounds__(256) grid_bwd_param_slide_kernel(GridMeta meta
 // (x enters the hash by xor, so x ^ 1 is the neighbour), parity of res * (y + z) for dense levels.
 // No cross-lane traffic: lane = (level, row-in-line, feature) owns its sums from first add to flush.
 // tools/scatter_model.py: 26.0 -> 22.7 requests per sample on a captured training batch.
-template <int CHUNK>
+template <int CHUNK, int MODE = 0>   // MODE bit 0 (A/B build): no atomics, the adds go to a per-lane sink (the kernel's ALU time)
 __global__ void __launch_bounds__(256) grid_bwd_param_line_kernel(GridMeta meta, const float* __restrict__ x,
                                                                   const float* __restrict__ dL_dy, int64_t lddy,
                                                                   const float* __restrict__ row_scale,
@@ -464,13 +466,15 @@ __global__ void __launch_bounds__(256) grid_bwd_param_line_kernel(GridMeta meta,
     float A0 = 0.0f, A1 = 0.0f, A2 = 0.0f, A3 = 0.0f, B0 = 0.0f, B1 = 0.0f, B2 = 0.0f, B3 = 0.0f;
     int b0 = 0, b1 = 0, b2 = 0;
     bool have = false;
+    float sink = 0.0f;   // MODE 1 only
 
     // (macros, not lambdas taking references: the sums must stay in registers)
 #define NGP_PUT(a_, gx_, gy_, gz_)                                                                      \
     do {                                                                                                \
         if ((a_) != 0.0f) {                                                                             \
             const uint32_t row_ = row_index(li, (uint32_t)(gx_), (uint32_t)(gy_), (uint32_t)(gz_));     \
-            atomicAdd(dtable + (size_t)row_ * F + f, (a_));                                             \
+            if (MODE & 1) sink += (a_) * (float)(row_ & 1023u);                                         \
+            else atomicAdd(dtable + (size_t)row_ * F + f, (a_));                                        \
         }                                                                                               \
         (a_) = 0.0f;                                                                                    \
     } while (0)
@@ -551,11 +555,282 @@ __global__ void __launch_bounds__(256) grid_bwd_param_line_kernel(GridMeta meta,
         NGP_FLUSH_SLOT(A0, B0, b0, b1, b2); NGP_FLUSH_SLOT(A1, B1, b0, b1 + 1, b2);
         NGP_FLUSH_SLOT(A2, B2, b0, b1, b2 + 1); NGP_FLUSH_SLOT(A3, B3, b0, b1 + 1, b2 + 1);
     }
+    if ((MODE & 1) && sink == 123.456f) dtable[lane] = sink;
+}
+
+// Experiment: the same walk with the per-sample body NOT unrolled (the product kernel above unrolls 8 samples
+// with every flush path: ~70 KB of code against a 64 KB instruction cache shared by two CUs).  The gradient
+// values run PF samples ahead in a register ring (rotation, no dynamic register index).
+// MODE bit 0: no atomics (the flush arithmetic stays, the adds go to a per-lane sink) — the kernel's ALU time.
+template <int CHUNK, int MODE>
+__global__ void __launch_bounds__(256) grid_bwd_param_line_rolled_kernel(GridMeta meta, const float* __restrict__ x,
+                                                                         const float* __restrict__ dL_dy, int64_t lddy,
+                                                                         const float* __restrict__ row_scale,
+                                                                         int64_t n, float* __restrict__ dtable)
+{
+    constexpr int F = 8;
+    constexpr int LV = 4;
+    const uint32_t L = meta.n_levels;
+    const uint32_t waves_per_chunk = (L + LV - 1) / LV;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t chunk = __builtin_amdgcn_readfirstlane((int)(wave_global / waves_per_chunk));
+    const uint32_t lg = __builtin_amdgcn_readfirstlane((int)(wave_global % waves_per_chunk));
+    const int lane = threadIdx.x & 63;
+    const uint32_t level = lg * LV + lane / (2 * F);
+    const int xb = (lane / F) & 1;
+    const int f = lane % F;
+    const int64_t s0 = chunk * CHUNK;
+    if (s0 >= n) return;
+    const int64_t s1 = s0 + CHUNK < n ? s0 + CHUNK : n;
+    const bool active = level < L;
+    const LevelInfo li = level_info(meta, active ? level : 0);
+    const size_t ld = (size_t)lddy;
+    const int odd = (!(li.flags & 1u) && (li.res & 1u)) ? 1 : 0;
+    float sink = 0.0f;
+
+    float A0 = 0.0f, A1 = 0.0f, A2 = 0.0f, A3 = 0.0f, B0 = 0.0f, B1 = 0.0f, B2 = 0.0f, B3 = 0.0f;
+    int b0 = 0, b1 = 0, b2 = 0;
+    bool have = false;
+
+    const float* gp = dL_dy + (size_t)(active ? level : 0) * F + f;
+    const int64_t last = s1 - 1;
+#define NGP_LOADG(s_) gp[(size_t)((s_) < last ? (s_) : last) * ld]
+#define NGP_LOADS(s_) (row_scale ? row_scale[(s_) < last ? (s_) : last] : 1.0f)
+    float gr0 = NGP_LOADG(s0), gr1 = NGP_LOADG(s0 + 1), gr2 = NGP_LOADG(s0 + 2), gr3 = NGP_LOADG(s0 + 3);
+    float sc0 = NGP_LOADS(s0), sc1 = NGP_LOADS(s0 + 1), sc2 = NGP_LOADS(s0 + 2), sc3 = NGP_LOADS(s0 + 3);
+    float qx = x[3 * s0], qy = x[3 * s0 + 1], qz = x[3 * s0 + 2];
+#pragma unroll 1
+    for (int64_t s = s0; s < s1; s++) {
+        const float gv = active ? gr0 * sc0 : 0.0f;
+        gr0 = gr1; gr1 = gr2; gr2 = gr3; gr3 = NGP_LOADG(s + 4);
+        sc0 = sc1; sc1 = sc2; sc2 = sc3; sc3 = NGP_LOADS(s + 4);
+        const float pxj = qx, pyj = qy, pzj = qz;
+        {
+            const int64_t sn = s + 1 < last ? s + 1 : last;
+            qx = x[3 * sn]; qy = x[3 * sn + 1]; qz = x[3 * sn + 2];
+        }
+        const float p0 = fmaf(li.scale, pxj, 0.5f), p1 = fmaf(li.scale, pyj, 0.5f), p2 = fmaf(li.scale, pzj, 0.5f);
+        const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+        const int g0 = (int)f0, g1 = (int)f1, g2 = (int)f2;
+        const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+        const int dx = g0 - b0, dy = g1 - b1, dz = g2 - b2;
+        if (have && (dx | dy | dz) != 0) {
+            const bool near_move = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+            if (!near_move) {
+                NGP_FLUSH_SLOT(A0, B0, b0, b1, b2); NGP_FLUSH_SLOT(A1, B1, b0, b1 + 1, b2);
+                NGP_FLUSH_SLOT(A2, B2, b0, b1, b2 + 1); NGP_FLUSH_SLOT(A3, B3, b0, b1 + 1, b2 + 1);
+            } else {
+                const bool fy0 = dy == 1, fy1 = dy == -1, fz0 = dz == 1, fz1 = dz == -1;
+                if (fy0 || fz0) NGP_FLUSH_SLOT(A0, B0, b0, b1, b2);
+                if (fy1 || fz0) NGP_FLUSH_SLOT(A1, B1, b0, b1 + 1, b2);
+                if (fy0 || fz1) NGP_FLUSH_SLOT(A2, B2, b0, b1, b2 + 1);
+                if (fy1 || fz1) NGP_FLUSH_SLOT(A3, B3, b0, b1 + 1, b2 + 1);
+                if (dy == 1) { A0 = A1; B0 = B1; A1 = 0.0f; B1 = 0.0f; A2 = A3; B2 = B3; A3 = 0.0f; B3 = 0.0f; }
+                else if (dy == -1) { A1 = A0; B1 = B0; A0 = 0.0f; B0 = 0.0f; A3 = A2; B3 = B2; A2 = 0.0f; B2 = 0.0f; }
+                if (dz == 1) { A0 = A2; B0 = B2; A2 = 0.0f; B2 = 0.0f; A1 = A3; B1 = B3; A3 = 0.0f; B3 = 0.0f; }
+                else if (dz == -1) { A2 = A0; B2 = B0; A0 = 0.0f; B0 = 0.0f; A3 = A1; B3 = B1; A1 = 0.0f; B1 = 0.0f; }
+                if (dx != 0) {
+                    NGP_STEP_X(A0, B0, b0, g0, g1, g2); NGP_STEP_X(A1, B1, b0, g0, g1 + 1, g2);
+                    NGP_STEP_X(A2, B2, b0, g0, g1, g2 + 1); NGP_STEP_X(A3, B3, b0, g0, g1 + 1, g2 + 1);
+                }
+            }
+        }
+        b0 = g0; b1 = g1; b2 = g2; have = true;
+        const float xw0 = (1 - w0) * gv, xw1 = w0 * gv;
+        const float y0 = 1 - w1, y1 = w1, z0 = 1 - w2, z1 = w2;
+#define NGP_LINE_ACC(A_, B_, Y_, Z_, WY_, WZ_)                                    \
+        {                                                                     \
+            const int q = (g0 - (odd & ((Y_) + (Z_)))) & 1;                   \
+            const float va = q ? (xb ? xw0 : 0.0f) : (xb ? xw1 : xw0);        \
+            const float vb = (q && !xb) ? xw1 : 0.0f;                         \
+            A_ = fmaf(va * (WY_), (WZ_), A_);                                 \
+            B_ = fmaf(vb * (WY_), (WZ_), B_);                                 \
+        }
+        NGP_LINE_ACC(A0, B0, g1, g2, y0, z0)
+        NGP_LINE_ACC(A1, B1, g1 + 1, g2, y1, z0)
+        NGP_LINE_ACC(A2, B2, g1, g2 + 1, y0, z1)
+        NGP_LINE_ACC(A3, B3, g1 + 1, g2 + 1, y1, z1)
+#undef NGP_LINE_ACC
+    }
+#undef NGP_LOADG
+#undef NGP_LOADS
+    if (have) {
+        NGP_FLUSH_SLOT(A0, B0, b0, b1, b2); NGP_FLUSH_SLOT(A1, B1, b0, b1 + 1, b2);
+        NGP_FLUSH_SLOT(A2, B2, b0, b1, b2 + 1); NGP_FLUSH_SLOT(A3, B3, b0, b1 + 1, b2 + 1);
+    }
+    if ((MODE & 1) && sink == 123.456f) dtable[lane] = sink;
 }
 #undef NGP_PUT
 #undef NGP_LINE_X
 #undef NGP_FLUSH_SLOT
 #undef NGP_STEP_X
+#endif  // NGP_AB_VARIANTS
+
+// Two-phase line scatter (F = 8).  The sliding-window kernel above spends its time in VALU work, not in atomic
+// requests (measured: 0.58 ms with the atomics compiled out against 0.70 ms with them, 237 VALU instructions per
+// wave and sample): the 16 lanes (row-in-line, feature) of a level all redo the same floor / delta / hash / window
+// arithmetic.  Here that arithmetic is done ONCE per (sample, level), in parallel:
+//   phase 1  lane = (level, sample-in-round): the cell of the sample on its level, the rows of its 8 corners, and per
+//            (y,z) corner slot the 64-byte LINES the two x-corners fall into (line id = row >> 1: rows 2k, 2k+1 share a
+//            request) with the trilinear weight each row-in-line takes — written to a wave-private LDS record
+//            together with the round's 16 x 32 gradient values;
+//   phase 2  lane = (level, row-in-line, feature), serial over the round's samples: per slot two running sums A / B
+//            tagged with their line ids.  A sum whose line is one of the new sample's two lines of the slot is kept
+//            (moved between A and B if the window stepped across a line), any other non-zero sum goes out as ONE
+//            atomic wave-instruction per line.  Slots are addressed by the ABSOLUTE parity of (y, z), so a window
+//            step in y or z moves no data: the rows that stay keep their slot, the ones that leave fail the tag
+//            compare.  No geometry cases (near / far moves, line parity of odd dense resolutions, hash or not): two
+//            corners that land in the same line are merged because they ARE the same line.
+// ~80 VALU instructions per wave and sample instead of 237; what remains is the memory-side request rate.
+// MODE bit 0 (A/B build): no atomics, the adds go to a per-lane sink.
+template <int CHUNK, int MODE = 0>
+__global__ void __launch_bounds__(256) grid_bwd_param_tag_kernel(GridMeta meta, const float* __restrict__ x,
+                                                                 const float* __restrict__ dL_dy, int64_t lddy,
+                                                                 const float* __restrict__ row_scale,
+                                                                 int64_t n, float* __restrict__ dtable)
+{
+    constexpr int F = 8;
+    constexpr int LV = 4;             // levels per wave
+    constexpr int R = 16;             // samples per round: 64 lanes = 16 samples x 4 levels in phase 1
+    constexpr int REC = 132;          // dwords per sample record (128 + 4: phase-1 stores of 8 lanes hit 8 x 4 banks)
+    constexpr uint32_t INVALID = 0xFFFFFFFFu;
+    // record: [0,16) tagA[lv][slot]  [16,32) tagB[lv][slot]  [32,64) wA[lv][xb][slot]  [64,96) wB[lv][xb][slot]
+    //         [96,128) g[lv][f]
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][R * REC];
+    uint32_t* W = lds[threadIdx.x >> 6];
+    const uint32_t L = meta.n_levels;
+    const uint32_t waves_per_chunk = (L + LV - 1) / LV;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t chunk = __builtin_amdgcn_readfirstlane((int)(wave_global / waves_per_chunk));
+    const uint32_t lg = __builtin_amdgcn_readfirstlane((int)(wave_global % waves_per_chunk));
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = chunk * CHUNK;
+    if (s0 >= n) return;
+    const int64_t s1 = s0 + CHUNK < n ? s0 + CHUNK : n;
+    const size_t ld = (size_t)lddy;
+
+    // phase-1 identity
+    const int lv1 = lane >> 4, j1 = lane & 15;
+    const uint32_t level1 = lg * LV + lv1;
+    const LevelInfo li = level_info(meta, level1 < L ? level1 : 0);
+    // gradient staging identity: lane -> (sample lane >> 2, 8 floats (lane & 3) * 8 .. + 7 of the wave's 32)
+    const int gs = lane >> 2, gq = lane & 3;
+    const bool g_ok = (lg * LV * F + gq * 8 + 8) <= L * F;   // the 8 floats belong to existing levels
+    // phase-2 identity
+    const int lv2 = lane >> 4, xb = (lane >> 3) & 1, f = lane & 7;
+    const uint32_t lane_off = (uint32_t)(xb * F + f);
+
+    float A[4] = {0.0f, 0.0f, 0.0f, 0.0f}, B[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t tA[4] = {INVALID, INVALID, INVALID, INVALID}, tB[4] = {INVALID, INVALID, INVALID, INVALID};
+    float sink = 0.0f;
+
+#define NGP_TAG_PUT(a_, t_)                                                            \
+    do {                                                                               \
+        if (MODE & 1) sink += (a_) * (float)((t_) & 1023u);                            \
+        else atomicAdd(dtable + (((t_) << 4) + lane_off), (a_));                       \
+    } while (0)
+
+    // prefetch of the first round
+    auto clampS = [&](int64_t s) { return s < s1 ? s : s1 - 1; };
+    float px, py, pz;
+    float4 ga, gb;
+    float gsc;
+    {
+        const int64_t s = clampS(s0 + j1);
+        px = x[3 * s]; py = x[3 * s + 1]; pz = x[3 * s + 2];
+        const int64_t sg = clampS(s0 + gs);
+        const float* gp = dL_dy + (size_t)sg * ld + lg * LV * F + gq * 8;
+        ga = g_ok ? *reinterpret_cast<const float4*>(gp) : make_float4(0, 0, 0, 0);
+        gb = g_ok ? *reinterpret_cast<const float4*>(gp + 4) : make_float4(0, 0, 0, 0);
+        gsc = row_scale ? row_scale[sg] : 1.0f;
+    }
+    for (int64_t sb = s0; sb < s1; sb += R) {
+        // ---------------- phase 1: one (sample, level) per lane
+        {
+            const float p0 = fmaf(li.scale, px, 0.5f), p1 = fmaf(li.scale, py, 0.5f), p2 = fmaf(li.scale, pz, 0.5f);
+            const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+            const int g0 = (int)f0, g1 = (int)f1, g2 = (int)f2;
+            const float w0 = p0 - f0, w1 = p1 - f1, w2 = p2 - f2;
+            uint32_t ta[4], tb[4];
+            float wa0[4], wa1[4], wb0[4], wb1[4];
+#pragma unroll
+            for (int slot = 0; slot < 4; slot++) {
+                const int cy = ((slot & 1) ^ g1) & 1, cz = ((slot >> 1) ^ g2) & 1;   // slot = absolute parity of (y, z)
+                const uint32_t r0 = row_index(li, (uint32_t)g0, (uint32_t)(g1 + cy), (uint32_t)(g2 + cz));
+                const uint32_t r1 = row_index(li, (uint32_t)(g0 + 1), (uint32_t)(g1 + cy), (uint32_t)(g2 + cz));
+                const float wyz = (cy ? w1 : 1 - w1) * (cz ? w2 : 1 - w2);
+                const float a0 = (1 - w0) * wyz, a1 = w0 * wyz;
+                const uint32_t l0 = r0 >> 1, l1 = r1 >> 1;
+                const bool same = l0 == l1;
+                const uint32_t b0 = r0 & 1u, b1 = r1 & 1u;
+                ta[slot] = l0;
+                tb[slot] = same ? INVALID : l1;
+                // weight of row-in-line 0 / 1 of line A, of line B
+                wa0[slot] = (b0 == 0 ? a0 : 0.0f) + ((same && b1 == 0) ? a1 : 0.0f);
+                wa1[slot] = (b0 == 1 ? a0 : 0.0f) + ((same && b1 == 1) ? a1 : 0.0f);
+                wb0[slot] = (!same && b1 == 0) ? a1 : 0.0f;
+                wb1[slot] = (!same && b1 == 1) ? a1 : 0.0f;
+            }
+            uint32_t* rec = W + j1 * REC;
+            *reinterpret_cast<uint4*>(rec + lv1 * 4) = make_uint4(ta[0], ta[1], ta[2], ta[3]);
+            *reinterpret_cast<uint4*>(rec + 16 + lv1 * 4) = make_uint4(tb[0], tb[1], tb[2], tb[3]);
+            *reinterpret_cast<float4*>(rec + 32 + lv1 * 8) = make_float4(wa0[0], wa0[1], wa0[2], wa0[3]);
+            *reinterpret_cast<float4*>(rec + 32 + lv1 * 8 + 4) = make_float4(wa1[0], wa1[1], wa1[2], wa1[3]);
+            *reinterpret_cast<float4*>(rec + 64 + lv1 * 8) = make_float4(wb0[0], wb0[1], wb0[2], wb0[3]);
+            *reinterpret_cast<float4*>(rec + 64 + lv1 * 8 + 4) = make_float4(wb1[0], wb1[1], wb1[2], wb1[3]);
+            float* grec = reinterpret_cast<float*>(W + gs * REC + 96 + gq * 8);
+            *reinterpret_cast<float4*>(grec) = make_float4(ga.x * gsc, ga.y * gsc, ga.z * gsc, ga.w * gsc);
+            *reinterpret_cast<float4*>(grec + 4) = make_float4(gb.x * gsc, gb.y * gsc, gb.z * gsc, gb.w * gsc);
+        }
+        // the next round's operands travel under phase 2
+        if (sb + R < s1) {
+            const int64_t s = clampS(sb + R + j1);
+            px = x[3 * s]; py = x[3 * s + 1]; pz = x[3 * s + 2];
+            const int64_t sg = clampS(sb + R + gs);
+            const float* gp = dL_dy + (size_t)sg * ld + lg * LV * F + gq * 8;
+            if (g_ok) { ga = *reinterpret_cast<const float4*>(gp); gb = *reinterpret_cast<const float4*>(gp + 4); }
+            gsc = row_scale ? row_scale[sg] : 1.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---------------- phase 2: serial over the round's samples
+        const int jmax = (int)((s1 - sb) < R ? (s1 - sb) : R);
+        const uint32_t* base = W + lv2 * 4;
+#pragma unroll 2
+        for (int j = 0; j < jmax; j++) {
+            const uint32_t* rec = base + j * REC;
+            const uint4 nA4 = *reinterpret_cast<const uint4*>(rec);
+            const uint4 nB4 = *reinterpret_cast<const uint4*>(rec + 16);
+            const float4 wA4 = *reinterpret_cast<const float4*>(rec + 32 + lv2 * 4 + xb * 4);
+            const float4 wB4 = *reinterpret_cast<const float4*>(rec + 64 + lv2 * 4 + xb * 4);
+            const float gv = *reinterpret_cast<const float*>(rec + 96 + lv2 * 4 + f);
+            const uint32_t nA[4] = {nA4.x, nA4.y, nA4.z, nA4.w}, nB[4] = {nB4.x, nB4.y, nB4.z, nB4.w};
+            const float wA[4] = {wA4.x, wA4.y, wA4.z, wA4.w}, wB[4] = {wB4.x, wB4.y, wB4.z, wB4.w};
+#pragma unroll
+            for (int slot = 0; slot < 4; slot++) {
+                const bool mAA = tA[slot] == nA[slot], mBA = tB[slot] == nA[slot];
+                const bool mAB = tA[slot] == nB[slot], mBB = tB[slot] == nB[slot];
+                if (!(mAA || mAB) && A[slot] != 0.0f) NGP_TAG_PUT(A[slot], tA[slot]);
+                if (!(mBA || mBB) && B[slot] != 0.0f) NGP_TAG_PUT(B[slot], tB[slot]);
+                const float keepA = mAA ? A[slot] : (mBA ? B[slot] : 0.0f);
+                const float keepB = mBB ? B[slot] : (mAB ? A[slot] : 0.0f);
+                A[slot] = fmaf(wA[slot], gv, keepA);
+                B[slot] = fmaf(wB[slot], gv, keepB);
+                tA[slot] = nA[slot];
+                tB[slot] = nB[slot];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int slot = 0; slot < 4; slot++) {
+        if (A[slot] != 0.0f) NGP_TAG_PUT(A[slot], tA[slot]);
+        if (B[slot] != 0.0f) NGP_TAG_PUT(B[slot], tB[slot]);
+    }
+#undef NGP_TAG_PUT
+    if ((MODE & 1) && sink == 123.456f) dtable[lane] = sink;
+}
 
 // ------------------------------------------------------------------ input gradient (H3)
 // GROUP = lanes that belong to one sample (L * LPI, a power of two <= 64): their partial
@@ -927,6 +1202,32 @@ int ngp_grid_bwd_param_scaled(const ngp_grid_desc* desc, const float* x, const f
                                lds_pad, st, m, x, dL_dy, lddy, n, dtable);
             return ngp_check_launch();
         }
+        // superseded sliding-window line kernel: 8 as it was, 1 without atomics, 2 / 3 rolled (with / without atomics);
+        // two-phase kernel: 4 with 32-sample chunks, 5 without atomics, 6 = product (64), 7 with 128-sample chunks
+        static const int line_mode = getenv("NGP_SCATTER_MODE") ? atoi(getenv("NGP_SCATTER_MODE")) : 0;
+        if (F == 8 && variant == 0 && line_mode != 0) {
+            const dim3 grid(ngp_blocks(waves2 * 64, 256));
+            if (line_mode == 8)
+                hipLaunchKernelGGL((grid_bwd_param_line_kernel<CHUNK, 0>), grid, dim3(256), 0, st, m, x, dL_dy, lddy, row_scale, n, dtable);
+            else if (line_mode == 1)
+                hipLaunchKernelGGL((grid_bwd_param_line_kernel<CHUNK, 1>), grid, dim3(256), 0, st, m, x, dL_dy, lddy, row_scale, n, dtable);
+            else if (line_mode == 2)
+                hipLaunchKernelGGL((grid_bwd_param_line_rolled_kernel<CHUNK, 0>), grid, dim3(256), 0, st, m, x, dL_dy, lddy, row_scale, n, dtable);
+            else if (line_mode == 3)
+                hipLaunchKernelGGL((grid_bwd_param_line_rolled_kernel<CHUNK, 1>), grid, dim3(256), 0, st, m, x, dL_dy, lddy, row_scale, n, dtable);
+            else if (line_mode == 4)
+                hipLaunchKernelGGL((grid_bwd_param_tag_kernel<CHUNK, 0>), grid, dim3(256), 0, st, m, x, dL_dy, lddy, row_scale, n, dtable);
+            else if (line_mode == 5)
+                hipLaunchKernelGGL((grid_bwd_param_tag_kernel<CHUNK, 1>), grid, dim3(256), 0, st, m, x, dL_dy, lddy, row_scale, n, dtable);
+            else if (line_mode == 6) {
+                const int64_t w = ((n + 63) / 64) * ((m.n_levels + 3) / 4);
+                hipLaunchKernelGGL((grid_bwd_param_tag_kernel<64, 0>), dim3(ngp_blocks(w * 64, 256)), dim3(256), 0, st, m, x, dL_dy, lddy, row_scale, n, dtable);
+            } else {
+                const int64_t w = ((n + 127) / 128) * ((m.n_levels + 3) / 4);
+                hipLaunchKernelGGL((grid_bwd_param_tag_kernel<128, 0>), dim3(ngp_blocks(w * 64, 256)), dim3(256), 0, st, m, x, dL_dy, lddy, row_scale, n, dtable);
+            }
+            return ngp_check_launch();
+        }
         static const int line_chunk = getenv("NGP_SCATTER_CHUNK") ? atoi(getenv("NGP_SCATTER_CHUNK")) : 32;
         if (F == 8 && variant == 0 && line_chunk != 32) {
             const int64_t w = ((n + line_chunk - 1) / line_chunk) * ((m.n_levels + 3) / 4);
@@ -942,10 +1243,12 @@ int ngp_grid_bwd_param_scaled(const ngp_grid_desc* desc, const float* x, const f
 #else
         const bool line = F == 8;
 #endif
-        if (line)    // F = 8 (the reference's tables): accumulate per 64-byte line
-            hipLaunchKernelGGL(grid_bwd_param_line_kernel<CHUNK>, dim3(ngp_blocks(waves2 * 64, 256)), dim3(256), 0, st,
+        if (line) {  // F = 8 (the reference's tables): accumulate per 64-byte line, two-phase kernel, 64-sample chunks
+            constexpr int TCHUNK = 64;
+            const int64_t wt = ((n + TCHUNK - 1) / TCHUNK) * ((m.n_levels + 3) / 4);
+            hipLaunchKernelGGL((grid_bwd_param_tag_kernel<TCHUNK, 0>), dim3(ngp_blocks(wt * 64, 256)), dim3(256), 0, st,
                                m, x, dL_dy, lddy, row_scale, n, dtable);
-        else
+        } else
             hipLaunchKernelGGL((grid_bwd_param_slide_kernel<F, CHUNK>), dim3(ngp_blocks(waves2 * 64, 256)), dim3(256),
                                0, st, m, x, dL_dy, lddy, row_scale, n, dtable);
     });
