@@ -62,6 +62,19 @@ def load():
     # called with the wrong argument lists.  build.py stamps the library with the digest of its sources:
     # a missing or stale library is rebuilt when hipcc is present, and refused otherwise.
     from . import build as _build
+    override = os.environ.get("NGP_LIB_OVERRIDE")
+    if override:
+        # A/B experiments only: a library built from ANOTHER revision with the same header (same-box comparisons
+        # of two kernel versions); the build-id check is skipped, the symbol check below is not
+        import sys
+        print(f"[ngp_amd] NGP_LIB_OVERRIDE: loading {override} without the build-id check", file=sys.stderr)
+        lib = C.CDLL(override)
+        for name, (restype, argl) in PROTOS.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = [t for t, _ in argl]
+        _lib = lib
+        return lib
     want = _build.source_id()
     if not os.path.exists(LIB_PATH) or _build.built_id() != want:
         if not _build.have_hipcc():

@@ -41,6 +41,10 @@ struct GemmArgs {
     const float* xf_W2; int64_t xf_ldw2;
     int xf_nout, xf_act;
     float* xf_dW2; int64_t xf_lddw2; float* xf_db2;   // XF WGRAD: also dW2 += dz2^T . hidden, db2 += colsum(dz2)
+#ifdef NGP_AB_VARIANTS
+    int exp;   // diagnostic switches of the streaming weight-gradient kernel (NGP_WGRAD_EXP): 1 no hand-over / atomics,
+               // 4 no operand transform (dz1 := hidden)
+#endif
 };
 
 // softplus(v) = log(1+e^v) with the hardware exp/log (v_exp_f32 / v_log_f32, ~1e-6 relative):
@@ -77,8 +81,10 @@ __device__ __forceinline__ float act_grad_from_output(float y, int act)
 // staging path of a GEMM (softplus' = 1 - exp(-y), v_exp_f32)
 __device__ __forceinline__ float act_grad_fast(float y, int act)
 {
-    if (act == NGP_ACT_SOFTPLUS)   // 1 - exp(-y) cancels for tiny y: two Taylor terms there (relative error < 2e-7)
-        return y < 1e-3f ? y * (1.0f - 0.5f * y) : 1.0f - __expf(-y);
+    if (act == NGP_ACT_SOFTPLUS) { // 1 - exp(-y) cancels for tiny y: two Taylor terms there (relative error < 2e-7)
+        const float e = __expf(-y), t = y * (1.0f - 0.5f * y);   // both sides evaluated: a select, not a branch
+        return y < 1e-3f ? t : 1.0f - e;
+    }
     return act == NGP_ACT_RELU ? (y > 0.0f ? 1.0f : 0.0f) : act_grad_from_output(y, act);
 }
 
@@ -734,6 +740,7 @@ __device__ __forceinline__ void stream_wait1(float& v)
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
 }
 
+
 template <int XF, int ACT1>
 __global__ void __launch_bounds__(512) mlp_stream_dgrad_kernel(GemmArgs p, int n_tiles)
 {
@@ -862,9 +869,11 @@ __global__ void __launch_bounds__(512) mlp_stream_dgrad_kernel(GemmArgs p, int n
 // needs hidden[s+lh][h0+li] and x[s+lh][32 tn + li] — plain dword loads, two 128-byte row segments
 // per instruction, no LDS, no barrier, no transposition.  A wave owns 32 hidden units and ALL input
 // columns (TN = 4 or 5 accumulator blocks), so every dz1 element is formed exactly once per
-// workgroup; W2's column for the lane's hidden unit stays in registers.  The loads run D steps ahead
-// in a register ring.  Samples past the end of the chunk are read from a clamped row with dz2 = 0,
-// which zeroes dz1 and with it every contribution.  dW2 / db2 / db1 ride along as per-lane sums.
+// workgroup; W2's column for the lane's hidden unit stays in registers.  The x loads run D steps ahead
+// in a register ring; hidden, dz2 and the remainder columns come in once per 16 samples as 16-byte pieces
+// and reach the lanes through a wave-private LDS tile (see "Operand traffic" below).  Samples past the end
+// of the chunk are read from a clamped row with dz2 = 0, which zeroes dz1 and with it every contribution.
+// dW2 / db2 / db1 ride along as per-lane sums.
 template <int XF, int ACT1, int TN, bool W2G>
 __global__ void __launch_bounds__(512) mlp_stream_wgrad_kernel(GemmArgs p, int64_t chunk)
 {
@@ -891,8 +900,7 @@ __global__ void __launch_bounds__(512) mlp_stream_wgrad_kernel(GemmArgs p, int64
     for (int o = 0; o < XF; o++) w2[o] = p.xf_W2[o * p.xf_ldw2 + h];
     // input columns of the lane: 4 li .. 4 li + 3 for the first four accumulator blocks (ONE 16-byte load per
     // sample instead of four dwords; which column a lane's accumulator stands for is free to choose),
-    // 128 + li for the fifth (clamped: a clamped column feeds an accumulator column that is never stored)
-    const int col5 = 128 + li < N ? 128 + li : N - 1;
+    // 128 + li for the fifth (columns past n_in read zeros and feed accumulator columns that are never stored)
     f32x16 acc[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; tn++)
@@ -902,40 +910,101 @@ __global__ void __launch_bounds__(512) mlp_stream_wgrad_kernel(GemmArgs p, int64
 #pragma unroll
     for (int o = 0; o < XF; o++) { gw[o] = 0.0f; gb2[o] = 0.0f; }
 
-    float ra[D], rb5[D], rd[D][XF];
-    f32x4 rb[D];
-    auto issue = [&](int d, int64_t s0) {
-        const int64_t s = s0 + lh;
-        const bool ok = s < kend;
-        const int64_t sc = ok ? s : kend - 1;
-        ra[d] = p.A[sc * p.lda + h];
-        rb[d] = *reinterpret_cast<const f32x4*>(p.B + sc * p.ldb + 4 * li);
-        if (TN > 4) rb5[d] = p.B[sc * p.ldb + col5];
+    // Operand traffic.  A wave-instruction costs the CU's address unit about the same whether it moves 256 bytes or
+    // 1 KB, and with 8 waves per CU three to six small loads per step (a dword of `hidden` = 2 x 128 bytes, XF
+    // broadcast dwords of dz2, a dword of the remainder columns) bound this loop, not the MFMAs (measured: 0.325 ->
+    // 0.179 ms with the loop's loads compiled out, nothing from dropping the transform or the hand-over).  So only x
+    // keeps a load per step (16 bytes per lane, 1 KB per instruction); `hidden`, the remainder columns and dz2 are
+    // fetched once per TURN of 16 samples as 16-byte pieces (one or two instructions each), parked in registers
+    // for a turn, then laid down in a wave-private LDS tile from which each step picks its operands with
+    // ds_read_b32 (LDS operations of one wave execute in order: no barrier).
+    static_assert(D == 8, "a turn of the staging tile is 16 samples = 8 steps");
+    float* stg = lds + (two ? (threadIdx.x >> 6) * 1152 : wave * 2048);
+    float* sH = stg;             // [16][32]  hidden[s][h0 + c]
+    float* sX5 = stg + 512;      // [16][32]  x[s][128 + c]
+    float* sD = stg + 1024;      // [16][4]   dz2[s][o] (0 past the end of the chunk), then 64 dummy words
+    const int hs = lane >> 3, hp = lane & 7;   // hidden piece: sample (two half-turns of 8), 16-byte piece of the 32 units
+    const int xs = lane >> 2, xp = lane & 3;   // remainder piece: sample, 16-byte piece of 16 columns
+    const int x5_second = (TN > 4 && N > 144) ? 16 : 0;   // 32 remainder columns (n_in = 160) or 16 (the piece twice)
+    // Prefetch by whole turns.  All loads of turn t+1 (8 x pieces, the hidden / remainder / dz2 pieces) are issued
+    // at the top of turn t and nothing of them is touched before the top of turn t+1, 8 steps (~4,000 cycles of
+    // MFMA work of the SIMD's two waves) later — so the one wait per turn the compiler places there (vmcnt(0): every
+    // load it waits for is a turn old) costs next to nothing, and no load is in flight across the loop's back-edge.
+    // A ROLLING ring (x piece of step d reloaded at step d, as this kernel used to do) looks cheaper in registers
+    // but cannot be expressed: the compiler's wait insertion merges the loop's two entry states and drains the whole
+    // ring at the first step of every turn, and inline-assembly loads with hand-placed counts are not safe either
+    // (the register allocator renames the ring across the back-edge and copies registers whose loads have not
+    // landed).  The loop body is one basic block (softplus' is a select, every lane takes part in every load and
+    // store); scheduling barriers keep the loads at the top of the turn and each step's MFMAs in their step.
+    f32x4 th0, th1, tx0, tx1;
+    float td;
+    auto clamp_row = [&](int64_t s) { return s < kend ? s : kend - 1; };
+    const bool d_lane = lane < 16 * XF;
+    const int d_s = d_lane ? lane / XF : 0, d_o = d_lane ? lane % XF : 0;
+    float* d_slot = sD + (d_lane ? d_s * 4 + d_o : 64 + lane);   // lanes without a dz2 element store to a dummy word
+    f32x4 xn[D], xc[D];
+    auto issue_turn = [&](int64_t t0) {
 #pragma unroll
-        for (int o = 0; o < XF; o++) {
-            const float v = p.xf_dz2[sc * p.xf_lddz2 + o];
-            rd[d][o] = ok ? v : 0.0f;
+        for (int d = 0; d < D; d++)
+            xn[d] = *reinterpret_cast<const f32x4*>(p.B + clamp_row(t0 + 2 * d + lh) * p.ldb + 4 * li);
+        th0 = *reinterpret_cast<const f32x4*>(p.A + clamp_row(t0 + hs) * p.lda + wave * 32 + 4 * hp);
+        th1 = *reinterpret_cast<const f32x4*>(p.A + clamp_row(t0 + 8 + hs) * p.lda + wave * 32 + 4 * hp);
+        if (TN > 4) {
+            const float* xr = p.B + clamp_row(t0 + xs) * p.ldb + 128 + 4 * xp;
+            tx0 = *reinterpret_cast<const f32x4*>(xr);
+            tx1 = *reinterpret_cast<const f32x4*>(xr + x5_second);   // n_in = 144: the same piece again
         }
+        td = p.xf_dz2[clamp_row(t0 + d_s) * p.xf_lddz2 + d_o];
     };
-    if (kbeg < kend) {
+    auto commit_turn = [&](int64_t t0) {
 #pragma unroll
-        for (int d = 0; d < D; d++) issue(d, kbeg + 2 * d);
-    }
+        for (int d = 0; d < D; d++) xc[d] = xn[d];
+        *reinterpret_cast<f32x4*>(sH + hs * 32 + 4 * hp) = th0;
+        *reinterpret_cast<f32x4*>(sH + (8 + hs) * 32 + 4 * hp) = th1;
+        if (TN > 4) {
+            *reinterpret_cast<f32x4*>(sX5 + xs * 32 + 4 * xp) = tx0;
+            *reinterpret_cast<f32x4*>(sX5 + xs * 32 + 16 + 4 * xp) = tx1;   // n_in = 144: columns that are never stored
+        }
+        *d_slot = (t0 + d_s < kend) ? td : 0.0f;
+    };
+#ifdef NGP_AB_VARIANTS
+    const int EXP = p.exp;
+#else
+    constexpr int EXP = 0;
+#endif
+    issue_turn(kbeg);   // (an empty group reads the clamped row kend - 1 >= 0 and never uses it)
     for (int64_t s0 = kbeg; s0 < kend; s0 += 2 * D) {
+        commit_turn(s0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_turn(s0 + 2 * D);
+        __builtin_amdgcn_sched_barrier(0);
+        // LDS operands one step ahead of the MFMAs that use them
+        float hidN = sH[lh * 32 + li], b5N = TN > 4 ? sX5[lh * 32 + li] : 0.0f, dzN[XF];
+#pragma unroll
+        for (int o = 0; o < XF; o++) dzN[o] = sD[lh * 4 + o];
 #pragma unroll
         for (int d = 0; d < D; d++) {
-            const float hid = ra[d];
+            const float hid = hidN, b5 = b5N;
             float b[TN], dz[XF];
 #pragma unroll
-            for (int tn = 0; tn < 4; tn++) b[tn] = rb[d][tn];
-            if (TN > 4) b[TN - 1] = rb5[d];
+            for (int o = 0; o < XF; o++) dz[o] = dzN[o];
+            if (d + 1 < D) {
+                const int j = 2 * (d + 1) + lh;
+                hidN = sH[j * 32 + li];
+                if (TN > 4) b5N = sX5[j * 32 + li];
 #pragma unroll
-            for (int o = 0; o < XF; o++) dz[o] = rd[d][o];
-            issue(d, s0 + 2 * d + 2 * D);
+                for (int o = 0; o < XF; o++) dzN[o] = sD[j * 4 + o];
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) b[tn] = xc[d][tn];
+            if (TN > 4) b[TN - 1] = b5;
             float sum = 0.0f;
 #pragma unroll
             for (int o = 0; o < XF; o++) sum = fmaf(dz[o], w2[o], sum);
-            const float a = sum * act_grad_fast(hid, ACT1);
+            float a = sum * act_grad_fast(hid, ACT1);
+#ifdef NGP_AB_VARIANTS
+            a = (EXP & 4) ? hid : a;
+#endif
             if (W2G) {
 #pragma unroll
                 for (int o = 0; o < XF; o++) {
@@ -946,7 +1015,20 @@ __global__ void __launch_bounds__(512) mlp_stream_wgrad_kernel(GemmArgs p, int64
             gb1 += a;
 #pragma unroll
             for (int tn = 0; tn < TN; tn++) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[tn], acc[tn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    __syncthreads();   // the staging tiles lie inside the regions the hand-over below writes
+    if (EXP & 1) {   // diagnostic: the loop alone (one store keeps the sums alive)
+        float t = gb1;
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) t += acc[tn][r];
+#pragma unroll
+        for (int o = 0; o < XF; o++) t += gw[o] + gb2[o];
+        if (t == 123.456f) p.C[lane] = t;
+        return;
     }
     // ---- the second group hands its sums to the first, lane for lane
     if (two) {
@@ -1810,8 +1892,12 @@ int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t
     p.vecA = aligned16(hidden) && (ldh % 4 == 0); p.vecB = aligned16(x) && (ldx % 4 == 0);
     p.xf_dz2 = dz2; p.xf_lddz2 = lddz2; p.xf_W2 = W2; p.xf_ldw2 = ldw2; p.xf_nout = n_out; p.xf_act = act1;
     p.xf_dW2 = dW2; p.xf_lddw2 = lddw2; p.xf_db2 = db2;
+#ifdef NGP_AB_VARIANTS
+    static const int wgrad_exp = getenv("NGP_WGRAD_EXP") ? atoi(getenv("NGP_WGRAD_EXP")) : 0;
+    p.exp = wgrad_exp;
+#endif
     static const bool stream_ok = !getenv("NGP_MLP_NO_STREAM") && !getenv("NGP_MLP_NO_STREAM_WGRAD");
-    if (stream_ok && H == 128 && (n_in == 128 || n_in == 144 || n_in == 160) && p.vecB &&
+    if (stream_ok && H == 128 && (n_in == 128 || n_in == 144 || n_in == 160) && p.vecA && p.vecB &&
         (act1 == NGP_ACT_RELU || act1 == NGP_ACT_SOFTPLUS)) {
         hipStream_t st = (hipStream_t)stream;
         static int n_cu = 0;
