@@ -350,6 +350,7 @@ class NGPTrainer:
                            and m.rgb_encoder._bound_valid and m.xyz_encoder._bound_valid)
             self._bound_step = False
             m._norm_bound_acc = None
+            zero_after = False
             with torch.cuda.stream(side):
                 if bounded:
                     lo = self._mlp_lo
@@ -362,8 +363,7 @@ class NGPTrainer:
                     # bound >= clip_norm (not seen in training): the exact norm after all, decided on the device
                     call("sumsq_if", self.flat_grad[0:lo], lo, self.scalars[0:1], self.need_exact)
                     call("clip_coef_if", self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2], self.need_exact)
-                    self.scalars[0:1].zero_()
-                    self.norm_acc.zero_()
+                    zero_after = True      # the two accumulators are cleared behind the Adam launches, not before them
                 elif early:
                     call("sumsq", self.flat_grad[b0:n], n - b0, self.scalars[0:1])
                 else:
@@ -384,6 +384,13 @@ class NGPTrainer:
                     ev = torch.cuda.Event()
                     ev.record(side)
                     events.append(ev)
+                if zero_after:
+                    self.scalars[0:1].zero_()
+                    self.norm_acc.zero_()
+                    # the next backward adds into both: it waits for this event (networks._FieldFn.backward)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    self.model._acc_zeroed = ev
             self.model._params_ready, self.model._rgb_params_ready = events
             return
         self.scalars.zero_()

@@ -360,11 +360,11 @@ def test_grid_fwd_bwd(ngp, case):
 
 @pytest.mark.parametrize("log2T", [14, 19])
 def test_grid_bwd_param_ray_ordered(ngp, log2T):
-    """The scatter keeps corner sums in a sliding 2x2x2 window while consecutive samples move by at
-    most one cell per axis.  Random points almost never do that, so this case feeds what training
-    feeds: samples marched along rays (step sqrt(3)/1024), in both directions along every axis,
-    axis-aligned rays (pure face moves), diagonal rays, a coarse-step ray (jumps of several cells ->
-    full flush), repeated positions, zero-gradient tails, ray boundaries inside a 32-sample chunk."""
+    """The scatter keeps per-line running sums while consecutive samples stay in (or step between) the same
+    64-byte lines.  Random points almost never do that, so this case feeds what training feeds: samples marched
+    along rays (step sqrt(3)/1024), in both directions along every axis, axis-aligned rays (pure face moves),
+    diagonal rays, a coarse-step ray (jumps of several cells: every sum leaves), repeated positions,
+    zero-gradient tails, ray boundaries inside a chunk."""
     from ngp_amd._lib import call
     L, Fd, base = 16, 8, 16
     pls = 1.3195079107728942
@@ -411,6 +411,33 @@ def test_grid_bwd_param_ray_ordered(ngp, log2T):
     out3 = torch.zeros(n_params, device=DEV)
     call("grid_bwd_param_scaled", gd, T(x), T(dy), L * Fd, T(rs), n, out3)
     close(N(out3), ref_s, 1e-4, 2e-5 * np.abs(ref_s).max())
+
+
+@pytest.mark.parametrize("L,n", [(1, 1), (5, 15), (6, 17), (16, 16), (16, 63), (7, 64), (16, 65), (10, 1000), (3, 129)])
+def test_grid_bwd_param_f8_edge_shapes(ngp, L, n):
+    """The F = 8 scatter works in rounds of 16 samples x 4 levels per wave and chunks of 64 samples: level counts that
+    are not multiples of four (idle level lanes), batches shorter than a round, ending inside a round or one sample
+    behind a chunk, repeated positions (one line hit by consecutive samples), and hash collisions of a tiny table."""
+    from ngp_amd._lib import call
+    Fd, base, pls, log2T = 8, 4, 1.7, 9
+    desc, n_params = oracle.grid_layout(L, Fd, log2T, base, pls)
+    g = rng(900 + 31 * L + n)
+    x = g.random((n, 3)).astype(np.float32)
+    if n > 4:
+        x[n // 2:n // 2 + 3] = x[n // 2]          # consecutive samples in one cell
+        x[-1] = [1.0, 1.0, 1.0]                    # the far corner (index wrap path)
+    dy = g.normal(size=(n, L * Fd)).astype(np.float32)
+    if n > 8:
+        dy[3:6] = 0.0
+    ref = oracle.grid_bwd_param(desc, x, dy, n_params)
+    gd = ngp._lib.GridDesc()
+    assert ngp._lib.call_host("grid_layout", L, Fd, log2T, base, pls, gd) == n_params
+    out = torch.zeros(n_params, device=DEV)
+    call("grid_bwd_param", gd, T(x), T(dy), L * Fd, n, out)
+    close(N(out), ref, 1e-4, 2e-5 * max(np.abs(ref).max(), 1e-6))
+    # accumulate: a second launch into the same buffer doubles it
+    call("grid_bwd_param", gd, T(x), T(dy), L * Fd, n, out)
+    close(N(out), 2 * ref, 1e-4, 4e-5 * max(np.abs(ref).max(), 1e-6))
 
 
 def test_grid_double_backward(ngp):
