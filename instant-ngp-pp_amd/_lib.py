@@ -62,10 +62,10 @@ def load():
     # called with the wrong argument lists.  build.py stamps the library with the digest of its sources:
     # a missing or stale library is rebuilt when hipcc is present, and refused otherwise.
     from . import build as _build
-    override = os.environ.get("NGP_LIB_OVERRIDE")
+    override = os.environ.get("NGP_LIB_OVERRIDE") if os.environ.get("NGP_AB_VARIANTS") else None
     if override:
-        # A/B experiments only: a library built from ANOTHER revision with the same header (same-box comparisons
-        # of two kernel versions); the build-id check is skipped, the symbol check below is not
+        # A/B experiments only (honoured with NGP_AB_VARIANTS=1): a library built from ANOTHER revision with the same
+        # header, for same-box comparisons of two kernel versions; the build-id check is skipped, the symbol check is not
         import sys
         print(f"[ngp_amd] NGP_LIB_OVERRIDE: loading {override} without the build-id check", file=sys.stderr)
         lib = C.CDLL(override)

@@ -438,6 +438,12 @@ def test_grid_bwd_param_f8_edge_shapes(ngp, L, n):
     # accumulate: a second launch into the same buffer doubles it
     call("grid_bwd_param", gd, T(x), T(dy), L * Fd, n, out)
     close(N(out), 2 * ref, 1e-4, 4e-5 * max(np.abs(ref).max(), 1e-6))
+    # a gradient matrix whose row stride is not a multiple of four floats (no 16-byte loads: the narrower-row kernel)
+    odd = np.zeros((n, L * Fd + 5), np.float32)
+    odd[:, :L * Fd] = dy
+    out2 = torch.zeros(n_params, device=DEV)
+    call("grid_bwd_param", gd, T(x), T(odd), L * Fd + 5, n, out2)
+    close(N(out2), ref, 1e-4, 2e-5 * max(np.abs(ref).max(), 1e-6))
 
 
 def test_grid_double_backward(ngp):
