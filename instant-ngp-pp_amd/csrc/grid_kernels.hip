@@ -98,7 +98,7 @@ template <> __device__ __forceinline__ float vec_dot<4>(const float (&g)[4], con
 }
 
 // ------------------------------------------------------------------ forward (H1)
-template <int F>
+template <int F, int EXP = 0>   // EXP (A/B build): 1 all rows from the first 1,024 of the table (cache hits), 2 no output store
 __global__ void __launch_bounds__(256) grid_fwd_kernel(GridMeta meta, const float* __restrict__ table,
                                                        const float* __restrict__ x, int64_t n_items,
                                                        float* __restrict__ y, int64_t ldy)
@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(256) grid_fwd_kernel(GridMeta meta, const floa
     for (int k = 0; k < 8; k++) {
         const uint32_t cx = k & 1, cy = (k >> 1) & 1, cz = (k >> 2) & 1;
         rows[k] = row_index(li, c.g[0] + cx, c.g[1] + cy, c.g[2] + cz);
+        if (EXP & 1) rows[k] &= 1023u;
         wts[k] = (cx ? c.w[0] : 1 - c.w[0]) * (cy ? c.w[1] : 1 - c.w[1]) * (cz ? c.w[2] : 1 - c.w[2]);
     }
     vec_t vals[8];
@@ -137,6 +138,7 @@ __global__ void __launch_bounds__(256) grid_fwd_kernel(GridMeta meta, const floa
     float* o = reinterpret_cast<float*>(&out);
 #pragma unroll
     for (int j = 0; j < V; j++) o[j] = acc[j];
+    if ((EXP & 2) && acc[0] != 123.456f) return;
     *reinterpret_cast<vec_t*>(y + sample * ldy + level * F + sub * V) = out;
 }
 
@@ -1153,6 +1155,16 @@ int ngp_grid_fwd(const ngp_grid_desc* desc, const float* table, const float* x, 
     hipStream_t st = (hipStream_t)stream;
     GRID_DISPATCH_F(m.n_features, {
         constexpr int LPI = F >= 4 ? F / 4 : 1;
+#ifdef NGP_AB_VARIANTS
+        static const int fwd_exp = getenv("NGP_GRID_FWD_EXP") ? atoi(getenv("NGP_GRID_FWD_EXP")) : 0;
+        if (F == 8 && fwd_exp) {
+            const dim3 grid(ngp_blocks(n_items * LPI, 256));
+            if (fwd_exp == 1) hipLaunchKernelGGL((grid_fwd_kernel<8, 1>), grid, dim3(256), 0, st, m, table, x, n_items, y, ldy);
+            else if (fwd_exp == 2) hipLaunchKernelGGL((grid_fwd_kernel<8, 2>), grid, dim3(256), 0, st, m, table, x, n_items, y, ldy);
+            else hipLaunchKernelGGL((grid_fwd_kernel<8, 3>), grid, dim3(256), 0, st, m, table, x, n_items, y, ldy);
+            return ngp_check_launch();
+        }
+#endif
         hipLaunchKernelGGL(grid_fwd_kernel<F>, dim3(ngp_blocks(n_items * LPI, 256)), dim3(256), 0, st, m, table, x,
                            n_items, y, ldy);
     });

@@ -33,9 +33,21 @@ captured = {}
 orig_call = _lib.call
 
 
+def keep(a):
+    """copy of a tensor argument WITH its row stride: the encoders write into / read from column windows of wider
+    matrices (rgb_in[:, 16:], row stride 144), and the replay passes the captured leading dimension"""
+    if not isinstance(a, torch.Tensor) or a.numel() >= 2e8:
+        return a
+    if a.dim() == 2 and not a.is_contiguous() and a.stride(1) == 1:
+        b = torch.zeros(a.shape[0], a.stride(0), dtype=a.dtype, device=a.device)
+        b[:, :a.shape[1]] = a
+        return b[:, :a.shape[1]]
+    return a.clone()
+
+
 def spy(name, *args):
     if name in ("grid_bwd_param", "grid_fwd", "grid_bwd_input") and captured.get("on"):
-        captured.setdefault(name, []).append(tuple(a.clone() if isinstance(a, torch.Tensor) and a.numel() < 2e8 else a for a in args))
+        captured.setdefault(name, []).append(tuple(keep(a) for a in args))
     return orig_call(name, *args)
 
 
