@@ -107,6 +107,73 @@ __global__ void __launch_bounds__(256) adam_span(float4* __restrict__ p, float4*
     }
 }
 
+// m and v interleaved per 16-byte quad ([m4 | v4] = 32 contiguous bytes): three read and three write streams
+// instead of four and four
+template <int UNROLL>
+__global__ void __launch_bounds__(256) adam_mv(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ mv,
+                                               float4* __restrict__ unused, int64_t n4, Hyper h, const float* __restrict__ gsp)
+{
+    const float gs = *gsp;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+        float4 P[UNROLL], G[UNROLL], M[UNROLL], V[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int64_t k = i + u * stride;
+            P[u] = p[k]; G[u] = g[k]; M[u] = mv[2 * k]; V[u] = mv[2 * k + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int64_t k = i + u * stride;
+            upd(P[u], G[u], M[u], V[u], h, gs);
+            p[k] = P[u]; mv[2 * k] = M[u]; mv[2 * k + 1] = V[u];
+            if (nz(G[u])) g[k] = zero4;
+        }
+    }
+}
+
+// everything in one array of [p4 | g4 | m4 | v4] records: one read and one write stream (not a layout the tables
+// can have — the gathers and the scatter need p and g as they are — but the ceiling of "fewer streams")
+template <int UNROLL>
+__global__ void __launch_bounds__(256) adam_aos(float4* __restrict__ a, float4* __restrict__ u1, float4* __restrict__ u2,
+                                                float4* __restrict__ u3, int64_t n4, Hyper h, const float* __restrict__ gsp)
+{
+    const float gs = *gsp;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+        float4 P[UNROLL], G[UNROLL], M[UNROLL], V[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int64_t k = (i + u * stride) * 4;
+            P[u] = a[k]; G[u] = a[k + 1]; M[u] = a[k + 2]; V[u] = a[k + 3];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int64_t k = (i + u * stride) * 4;
+            upd(P[u], G[u], M[u], V[u], h, gs);
+            a[k] = P[u]; a[k + 2] = M[u]; a[k + 3] = V[u];
+            if (nz(G[u])) a[k + 1] = zero4;
+        }
+    }
+}
+
+// the sweep without its arithmetic and without the gradient's zero-fill: 16 B read, 12 B written per parameter
+__global__ void __launch_bounds__(256) copy_4r3w(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
+                                                 float4* __restrict__ v, int64_t n4, Hyper h, const float* __restrict__ gsp)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + stride < n4; i += 2 * stride) {
+        const int64_t k = i + stride;
+        float4 a = p[i], b = g[i], c = m[i], d = v[i], e = p[k], f = g[k], q = m[k], r = v[k];
+        a.x += b.x; e.x += f.x;
+        p[i] = a; m[i] = d; v[i] = c; p[k] = e; m[k] = r; v[k] = q;
+    }
+}
+
 __global__ void fill_grad(float4* g, int64_t n4, float frac_nz)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -146,6 +213,32 @@ int main()
         printf("%-44s blocks %5d  %7.3f ms  %6.2f TB/s (28 B/param)\n", label, BLOCKS, best, bytes / best / 1e9); \
     }
     RUN("stride x2 (shipped shape)", (adam_stride<2, false>), 512);
+    RUN("copy 4 read / 3 write streams, no arithmetic", copy_4r3w, 512);
+    RUN("copy 4 read / 3 write streams, no arithmetic", copy_4r3w, 1024);
+    {   // m / v interleaved: the m buffer holds both (v is free for the duration)
+        float4* mv; CHECK(hipMalloc(&mv, n * 8)); CHECK(hipMemset(mv, 0, n * 8));
+        float4* keep = m; m = mv;
+        RUN("m / v interleaved x2", (adam_mv<2>), 512);
+        RUN("m / v interleaved x2", (adam_mv<2>), 1024);
+        RUN("m / v interleaved x4", (adam_mv<4>), 512);
+        m = keep; CHECK(hipFree(mv));
+    }
+    {   // one array of records
+        float4* a; CHECK(hipMalloc(&a, n * 16)); CHECK(hipMemset(a, 0, n * 16));
+        float4* keep = p; p = a;
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; rep++) {
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL((adam_aos<2>), dim3(512), dim3(256), 0, 0, p, g, m, v, n4, h, gs);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < best) best = ms;
+        }
+        printf("%-44s blocks %5d  %7.3f ms  %6.2f TB/s (28 B/param; gradient all zero: no zero-fill)\n", "array of [p g m v] records x2", 512, best, bytes / best / 1e9);
+        p = keep; CHECK(hipFree(a));
+    }
     RUN("stride x2", (adam_stride<2, false>), 1024);
     RUN("stride x2", (adam_stride<2, false>), 2048);
     RUN("stride x2", (adam_stride<2, false>), 8192);
