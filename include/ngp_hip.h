@@ -252,6 +252,31 @@ int ngp_neg_normalize_bwd(const float* x, int64_t ldx, const float* dL_dy, int64
                           void* stream);
 
 /* ------------------------------------------------------------------------
+ * Live samples of a marched batch (no counterpart in the reference: it evaluates the colour branch on every
+ * sample and lets composite_train_fw, volumerendering.cu:84-114, ignore those behind the early-termination
+ * point).  ngp_live_rows decides, with the compositing kernels' own transmittance bookkeeping, which samples of
+ * every ray take part (all up to and including the one at which T <= T_threshold) and writes
+ *   offsets  (n_rays)  scratch: first position of the ray's live samples in the list
+ *   live_idx (N)       the first *n_live entries: ascending sample rows that take part
+ *   inv_idx  (N)       position of a sample in that list, -1 for a sample behind its ray's stop
+ *   n_live   (1)       device word (copy it to the host to size the compacted launches)
+ * rays_a must cover every sample row (the marcher's output does).  Up to two dense (N,3) row blocks (positions,
+ * directions) are moved into the compacted order on the way.  ngp_gather_rows / ngp_spread_rows(3) move (n, cols)
+ * row blocks into / out of the compacted order (spread writes zeros to rows that are not in the list; the
+ * three-block form takes dense blocks, leading dimension = cols).
+ * ---------------------------------------------------------------------- */
+int ngp_live_rows(const float* sigmas, const float* deltas, const int64_t* rays_a, float T_threshold,
+                  int64_t n_rays, int32_t* offsets, int32_t* live_idx, int32_t* inv_idx, int32_t* n_live,
+                  const float* a3 /* (N,3) or NULL */, float* a3_compact, const float* b3 /* (N,3) or NULL */,
+                  float* b3_compact, void* stream);
+int ngp_spread_rows3(const float* src0, int cols0, float* dst0, const float* src1, int cols1, float* dst1,
+                     const float* src2, int cols2, float* dst2, const int32_t* inv_idx, int64_t n, void* stream);
+int ngp_gather_rows(const float* src, int64_t ld_src, int cols, const int32_t* idx, int64_t n_out, float* dst,
+                    int64_t ld_dst, void* stream);
+int ngp_spread_rows(const float* src, int64_t ld_src, int cols, const int32_t* inv_idx, int64_t n, float* dst,
+                    int64_t ld_dst, void* stream);
+
+/* ------------------------------------------------------------------------
  * R4  torch_scatter.segment_csr(src, indptr) with sum reduction
  * (custom_functions.py:110-112).  src (n_rows, width), indptr (n_seg+1) i64.
  * ---------------------------------------------------------------------- */

@@ -544,6 +544,121 @@ inline dim3 seg_grid(int n_rays) { return dim3(ngp_blocks((int64_t)n_rays * 32, 
 
 } // namespace
 
+// ------------------------------------------------------------------ live samples of a marched batch
+// A ray's samples behind its early-termination point (T <= T_threshold, volumerendering.cu:111) carry zero weight
+// and receive zero gradient; the density head has to see them (the stop depends on their predecessors' sigma), the
+// colour branch and its backward do not.  Three launches turn (sigma, delta, rays_a) into the ascending list of the
+// rows that DO take part, with the very bookkeeping the compositing kernels use (chunk_alpha: same scan, same
+// comparison, same bits), so the compositor never reads a colour the list left out.
+__global__ void live_count_kernel(const float* __restrict__ sigmas, const float* __restrict__ deltas,
+                                  const int64_t* __restrict__ rays_a, float T_thr, int n_rays, int32_t* __restrict__ counts)
+{
+    Seg sg; int lane;
+    if (!seg_load(rays_a, n_rays, sg, lane)) return;
+    float T_run = 1.0f;
+    int live = sg.n;
+    for (int k0 = 0; k0 < sg.n; k0 += 32) {
+        const int k = k0 + lane;
+        const Chunk c = chunk_alpha(sigmas, deltas, sg.start + k, k < sg.n, T_run, T_thr, lane);
+        if (c.first >= 0) { live = k0 + c.first + 1; break; }
+        T_run = __shfl(c.T_after, 31, 32);
+    }
+    if (lane == 0) counts[(blockIdx.x * blockDim.x + threadIdx.x) >> 5] = live;
+}
+
+// exclusive scan of the per-ray counts in place (one workgroup, fixed order), total to *n_live
+__global__ void __launch_bounds__(1024) live_scan_kernel(int32_t* __restrict__ counts, int n_rays, int32_t* __restrict__ n_live)
+{
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n_rays; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int32_t v = i < n_rays ? counts[i] : 0;
+        int32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int32_t before = carry_s;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        if (i < n_rays) counts[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_live = carry_s;
+}
+
+// (also moves up to two (N,3) row blocks — the positions and directions the colour branch starts from — into the
+// compacted order: a ray's live rows are one contiguous run on both sides)
+__global__ void live_fill_kernel(const int64_t* __restrict__ rays_a, int n_rays, const int32_t* __restrict__ offsets,
+                                 const int32_t* __restrict__ n_live_total, int32_t* __restrict__ live_idx,
+                                 int32_t* __restrict__ inv_idx, const float* __restrict__ a3, float* __restrict__ a3_c,
+                                 const float* __restrict__ b3, float* __restrict__ b3_c)
+{
+    Seg sg; int lane;
+    if (!seg_load(rays_a, n_rays, sg, lane)) return;
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int32_t off = offsets[row];
+    const int32_t end = row + 1 < n_rays ? offsets[row + 1] : *n_live_total;
+    const int live = end - off;
+    for (int k = lane; k < sg.n; k += 32) {
+        const int64_t s = sg.start + k;
+        if (k < live) { live_idx[off + k] = (int32_t)s; inv_idx[s] = off + k; }
+        else inv_idx[s] = -1;
+    }
+    for (int e = lane; e < 3 * live; e += 32) {
+        if (a3) a3_c[3 * (int64_t)off + e] = a3[3 * sg.start + e];
+        if (b3) b3_c[3 * (int64_t)off + e] = b3[3 * sg.start + e];
+    }
+}
+
+// up to three row blocks at once (the colour branch's outputs back in sample order)
+__global__ void spread_rows3_kernel(const float* __restrict__ s0, int c0, float* __restrict__ d0,
+                                    const float* __restrict__ s1, int c1, float* __restrict__ d1,
+                                    const float* __restrict__ s2, int c2, float* __restrict__ d2,
+                                    const int32_t* __restrict__ inv, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t j = inv[i];
+        for (int c = 0; c < c0; c++) d0[i * c0 + c] = j >= 0 ? s0[j * c0 + c] : 0.0f;
+        for (int c = 0; c < c1; c++) d1[i * c1 + c] = j >= 0 ? s1[j * c1 + c] : 0.0f;
+        for (int c = 0; c < c2; c++) d2[i * c2 + c] = j >= 0 ? s2[j * c2 + c] : 0.0f;
+    }
+}
+
+// dst[j, 0:cols] = src[idx[j], 0:cols]
+__global__ void gather_rows_kernel(const float* __restrict__ src, int64_t ld_src, int cols, const int32_t* __restrict__ idx,
+                                   int64_t n_out, float* __restrict__ dst, int64_t ld_dst)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_out * cols; e += stride) {
+        const int64_t j = e / cols;
+        const int c = (int)(e - j * cols);
+        dst[j * ld_dst + c] = src[(int64_t)idx[j] * ld_src + c];
+    }
+}
+
+// dst[i, 0:cols] = inv[i] >= 0 ? src[inv[i], 0:cols] : 0
+__global__ void spread_rows_kernel(const float* __restrict__ src, int64_t ld_src, int cols, const int32_t* __restrict__ inv,
+                                   int64_t n, float* __restrict__ dst, int64_t ld_dst)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n * cols; e += stride) {
+        const int64_t i = e / cols;
+        const int c = (int)(e - i * cols);
+        const int32_t j = inv[i];
+        dst[i * ld_dst + c] = j >= 0 ? src[(int64_t)j * ld_src + c] : 0.0f;
+    }
+}
+
 extern "C" {
 
 int ngp_composite_alpha_fw(const float* sigmas, const float* deltas, const int64_t* rays_a, float T_threshold,
@@ -734,6 +849,63 @@ int ngp_segment_csr_sum(const float* src, const int64_t* indptr, int n_seg, int 
     if (!indptr || !out) return NGP_EINVAL;
     hipLaunchKernelGGL(segment_csr_kernel, seg_grid(n_seg), dim3(256), 0, (hipStream_t)stream, src, indptr, n_seg,
                        width, out);
+    return ngp_check_launch();
+}
+
+int ngp_live_rows(const float* sigmas, const float* deltas, const int64_t* rays_a, float T_threshold, int64_t n_rays,
+                  int32_t* offsets, int32_t* live_idx, int32_t* inv_idx, int32_t* n_live, const float* a3, float* a3_c,
+                  const float* b3, float* b3_c, void* stream)
+{
+    if ((a3 && !a3_c) || (b3 && !b3_c)) return NGP_EINVAL;
+    if (n_rays < 0 || n_rays > 0x7fffff00) return NGP_EINVAL;
+    if (!n_live) return NGP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_rays == 0) return hipMemsetAsync(n_live, 0, sizeof(int32_t), st) == hipSuccess ? NGP_OK : NGP_ELAUNCH;
+    if (!sigmas || !deltas || !rays_a || !offsets || !live_idx || !inv_idx) return NGP_EINVAL;
+    hipLaunchKernelGGL(live_count_kernel, seg_grid((int)n_rays), dim3(256), 0, st, sigmas, deltas, rays_a, T_threshold,
+                       (int)n_rays, offsets);
+    hipLaunchKernelGGL(live_scan_kernel, dim3(1), dim3(1024), 0, st, offsets, (int)n_rays, n_live);
+    hipLaunchKernelGGL(live_fill_kernel, seg_grid((int)n_rays), dim3(256), 0, st, rays_a, (int)n_rays, offsets, n_live,
+                       live_idx, inv_idx, a3, a3_c, b3, b3_c);
+    return ngp_check_launch();
+}
+
+int ngp_spread_rows3(const float* src0, int cols0, float* dst0, const float* src1, int cols1, float* dst1,
+                     const float* src2, int cols2, float* dst2, const int32_t* inv_idx, int64_t n, void* stream)
+{
+    if (n < 0 || cols0 < 0 || cols1 < 0 || cols2 < 0) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!inv_idx || (cols0 && !dst0) || (cols1 && !dst1) || (cols2 && !dst2)) return NGP_EINVAL;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(spread_rows3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src0, cols0, dst0,
+                       src1, cols1, dst1, src2, cols2, dst2, inv_idx, n);
+    return ngp_check_launch();
+}
+
+int ngp_gather_rows(const float* src, int64_t ld_src, int cols, const int32_t* idx, int64_t n_out, float* dst,
+                    int64_t ld_dst, void* stream)
+{
+    if (n_out < 0 || cols < 1 || ld_src < cols || ld_dst < cols) return NGP_EINVAL;
+    if (n_out == 0) return NGP_OK;
+    if (!src || !idx || !dst) return NGP_EINVAL;
+    int64_t blocks = (n_out * cols + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, cols,
+                       idx, n_out, dst, ld_dst);
+    return ngp_check_launch();
+}
+
+int ngp_spread_rows(const float* src, int64_t ld_src, int cols, const int32_t* inv_idx, int64_t n, float* dst,
+                    int64_t ld_dst, void* stream)
+{
+    if (n < 0 || cols < 1 || ld_src < cols || ld_dst < cols) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!inv_idx || !dst) return NGP_EINVAL;   // src may be NULL when no row is live (every inv is -1)
+    int64_t blocks = (n * cols + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(spread_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, cols,
+                       inv_idx, n, dst, ld_dst);
     return ngp_check_launch();
 }
 

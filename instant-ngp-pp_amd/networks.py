@@ -88,6 +88,20 @@ _FUSED_BWD_MAX_OUT = int(_os.environ.get("NGP_FUSED_BWD_MAX_OUT", "3"))
 _SIDE = {}
 _SIDE_FWD = {}
 _FWD_OVERLAP = _os.environ.get("NGP_NO_FWD_OVERLAP", "0") != "1"   # A/B: the colour branch of the forward on its own stream
+_COMPACT = _os.environ.get("NGP_NO_COMPACT", "0") != "1"           # A/B: colour branch on the live samples only
+_SCATTER_AFTER_DGRAD = _os.environ.get("NGP_SCATTER_AFTER_DGRAD", "0") == "1"   # A/B: density scatter held back behind the colour data gradient
+
+
+_PINNED = {}
+
+
+def _pinned_word(dev):
+    """one pinned int32 per device: the landing place of a device-side count the host has to read"""
+    key = torch.device(dev).index
+    t = _PINNED.get(key)
+    if t is None:
+        t = _PINNED[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    return t
 
 
 def _fwd_stream(dev):
@@ -260,6 +274,14 @@ class _FieldFn(Function):
         Kp = model.rgb_net.padded_in
         span = model._span()
         xn = (x - model.xyz_min).div_(span)
+        # Samples behind their ray's early-termination point take no part in the image and get no gradient: when the
+        # renderer hands over the rays' segments (model._live_ctx), the colour branch and its backward run on the
+        # live samples only.  The density head needs every sample (the stop depends on sigma); the list of live rows
+        # comes from the compositor's own bookkeeping (ngp_live_rows), its length reaches the host through a pinned
+        # word while the device works on the analytic normals.
+        live = getattr(model, "_live_ctx", None)
+        compact = bool(_COMPACT and live is not None and n > 0 and embed_a is None and x.is_cuda
+                       and not ctx.needs_input_grad[1])
         # every buffer comes from the caller's stream (the allocator then knows them as that stream's; the colour
         # stream below only launches into them and is joined before anything is returned)
         feat = torch.empty(n, 128, dtype=_f32, device=dev)
@@ -267,20 +289,34 @@ class _FieldFn(Function):
         sig = torch.empty(n, 1, dtype=_f32, device=dev)
         dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
         grads = torch.empty(n, 3, dtype=_f32, device=dev)   # d sigma / d xn (normalised coordinates)
-        rgb_in = torch.empty(n, Kp, dtype=_f32, device=dev)
-        a_r = torch.empty(n, 128, dtype=_f32, device=dev)
         rgb_o = torch.empty(n, 3, dtype=_f32, device=dev)
-        a_n = torch.empty(n, 32, dtype=_f32, device=dev)
         np_o = torch.empty(n, 3, dtype=_f32, device=dev)
-        a_s = torch.empty(n, 32, dtype=_f32, device=dev)
         sem_o = torch.empty(n, C, dtype=_f32, device=dev)
         dz2 = torch.empty(n, 1, dtype=_f32, device=dev) if _FUSED_BWD else None
         dz1 = None if _FUSED_BWD else torch.empty(n, 128, dtype=_f32, device=dev)
-        feat_rgb = rgb_in[:, 16:144]
         net = model.rgb_net
+        bufs = {}
+
+        def colour_buffers(m):
+            bufs["rgb_in"] = torch.empty(m, Kp, dtype=_f32, device=dev)
+            bufs["a_r"] = torch.empty(m, 128, dtype=_f32, device=dev)
+            bufs["a_n"] = torch.empty(m, 32, dtype=_f32, device=dev)
+            bufs["a_s"] = torch.empty(m, 32, dtype=_f32, device=dev)
+            if compact:   # compacted outputs; rgb_o / np_o / sem_o are filled from them
+                bufs["rgb_c"] = torch.empty(m, 3, dtype=_f32, device=dev)
+                bufs["np_c"] = torch.empty(m, 3, dtype=_f32, device=dev)
+                bufs["sem_c"] = torch.empty(m, C, dtype=_f32, device=dev)
 
         def colour_branch():
             # [SH(16) | rgb grid features (128) | appearance code (E) | ones-padding] -> rgb_net, the two heads
+            n, rgb_in, a_r, a_n, a_s = bufs["n"], bufs["rgb_in"], bufs["a_r"], bufs["a_n"], bufs["a_s"]
+            feat_rgb = rgb_in[:, 16:144]
+            if compact:   # (positions and directions came over with the list, see ngp_live_rows)
+                xn, d = bufs["xn_c"][:n], bufs["d_c"][:n]
+                rgb_o, np_o, sem_o = bufs["rgb_c"], bufs["np_c"], bufs["sem_c"]
+            else:
+                xn, d = bufs["xn_full"], bufs["d_full"]
+                rgb_o, np_o, sem_o = bufs["rgb_o"], bufs["np_o"], bufs["sem_o"]
             call("sh_fwd_dirs", d, n, 4, rgb_in, Kp)
             _wait_params(model)   # the colour table's Adam piece (the stream this runs on waits for it)
             call("grid_fwd", re.desc, rgb_table, xn, n, rgb_in[:, 16:], Kp)
@@ -304,13 +340,19 @@ class _FieldFn(Function):
             else:
                 call("linear_fwd", feat_rgb, Kp, sem_p, 128, None, n, 128, 32, _RELU, a_s, 32, None)
                 call("linear_fwd", a_s, 32, sem_p[32 * 128:], 32, None, n, 32, C, _NONE, sem_o, C, None)
+            if compact:   # back to sample order, zeros behind the stops
+                call("spread_rows3", rgb_o, 3, bufs["rgb_o"], np_o, 3, bufs["np_o"], sem_o, C, bufs["sem_o"],
+                     bufs["inv_idx"], bufs["n_full"])
 
+        bufs.update(xn_full=xn, d_full=d, rgb_o=rgb_o, np_o=np_o, sem_o=sem_o, n_full=n, n=n)
         # The colour branch needs the positions and the colour table, nothing of the density path: it runs on a
         # stream of its own from the moment the colour table's Adam piece is done, beside the rest of the density
-        # path and the analytic normals (which are stretched beyond that piece's end on one stream).
+        # path and the analytic normals (which are stretched beyond that piece's end on one stream).  (Compacted: it
+        # also needs the list of live rows, i.e. sigma — it starts behind the density head, beside the normals.)
         main = torch.cuda.current_stream()
         side = _fwd_stream(dev) if (_FWD_OVERLAP and x.is_cuda) else None
-        if side is not None:
+        if side is not None and not compact:
+            colour_buffers(n)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 colour_branch()
@@ -322,6 +364,22 @@ class _FieldFn(Function):
         else:
             call("linear_fwd", feat, 128, W1, 128, b1, n, 128, 128, _SOFTPLUS, a1, 128, None)
             call("linear_fwd", a1, 128, W2, 128, b2, n, 128, 1, _SOFTPLUS, sig, 1, None)
+        live_ev = None
+        if compact:
+            rays_a, deltas, T_thr = live
+            n_rays = rays_a.shape[0]
+            offsets = torch.empty(n_rays, dtype=torch.int32, device=dev)
+            bufs["live_idx"] = torch.empty(n, dtype=torch.int32, device=dev)
+            bufs["inv_idx"] = torch.empty(n, dtype=torch.int32, device=dev)
+            n_live_dev = torch.empty(1, dtype=torch.int32, device=dev)
+            bufs["xn_c"] = torch.empty(n, 3, dtype=_f32, device=dev)   # the first n_live rows are used
+            bufs["d_c"] = torch.empty(n, 3, dtype=_f32, device=dev)
+            call("live_rows", sig, deltas.contiguous(), rays_a, float(T_thr), n_rays, offsets, bufs["live_idx"],
+                 bufs["inv_idx"], n_live_dev, xn, bufs["xn_c"], d, bufs["d_c"])
+            n_live_host = _pinned_word(dev)
+            n_live_host.copy_(n_live_dev, non_blocking=True)
+            live_ev = torch.cuda.Event()
+            live_ev.record(main)
         # analytic d(sigma)/dx: back-substitute ones through the head, then the grid input gradient
         if _FUSED_BWD:
             call("act_bwd", None, sig, n, _SOFTPLUS, dz2)          # upstream gradient = ones
@@ -334,13 +392,31 @@ class _FieldFn(Function):
         # dfeat = d(sigma)/d(features) is kept: the density head has ONE output, so the gradient the backward
         # sends into the density encoder is d_sigma[s] * dfeat[s] — no second data-gradient product there
 
+        if compact:
+            # the host learns the number of live rows while the device is busy with the normals (and the optimizer
+            # stream with the colour table); the colour branch is then enqueued with exactly that many rows
+            live_ev.synchronize()
+            n_c = int(n_live_host[0])
+            bufs["n"] = n_c
+            colour_buffers(n_c)
+            if side is not None:
+                side.wait_event(live_ev)
+                with torch.cuda.stream(side):
+                    colour_branch()
+            else:
+                colour_branch()
         if side is not None:
             main.wait_stream(side)
-        else:
+        elif not compact:
+            colour_buffers(n)
             colour_branch()
+        rgb_in, a_r, a_n, a_s = bufs["rgb_in"], bufs["a_r"], bufs["a_n"], bufs["a_s"]
 
         ctx.model = model
         ctx.E, ctx.K, ctx.Kp, ctx.C = E, K, Kp, C
+        ctx.compact = compact
+        if compact:
+            ctx.live = (bufs["live_idx"], bufs["xn_c"][:bufs["n"]], bufs["rgb_c"], bufs["np_c"], bufs["sem_c"], bufs["n"])
         ctx.save_for_backward(xn, feat, a1, sig, rgb_in, a_r, rgb_o, a_n, np_o, a_s, sem_o,
                               xyz_table, W1, W2, rgb_table, rgb_p, nrm_p, sem_p, dfeat)
         ctx.mark_non_differentiable(grads)
@@ -407,7 +483,7 @@ class _FieldFn(Function):
             d_sig_c = d_sig.contiguous()
             buf, g_xyz = table_buffer(xe, xyz_table)
 
-            def density_scatter():
+            def density_scatter(n=n):   # (bound now: the colour branch below may work on fewer rows)
                 call("grid_bwd_param_scaled", xe.desc, xn, dsig_dfeat, 128, d_sig_c, n, buf)
                 cb = getattr(xe, "on_grad_ready", None)
                 if cb is not None:
@@ -416,13 +492,36 @@ class _FieldFn(Function):
             # its scatter is enqueued, so there the colour scatter leads on the side stream and the density scatter
             # follows it — the collective then runs under the density scatter and the weight products.
             density_later = bool(getattr(re, "grad_ready_is_collective", False)) and d_rgb is not None and need[9]
-            if not density_later:
+            # One GPU: the density scatter leads on the side stream and is let loose at once.  It becomes ready together
+            # with the colour branch's data gradient, and whichever reaches the CUs first keeps them (the product takes
+            # 0.15 ms when its 256 large workgroups are placed first, 0.4-0.6 ms behind the scatter's thousands of
+            # small ones).  Holding the scatter back behind the product (NGP_SCATTER_AFTER_DGRAD=1) makes that
+            # deterministic and is still the slower schedule: +0.04 ms/step (A/B, 3 alternations of 100 steps), the
+            # scatters are the longer path and every microsecond they start later is lost.
+            density_after_dgrad = not density_later and d_rgb is not None and _SCATTER_AFTER_DGRAD
+            if not density_later and not density_after_dgrad:
                 on_side(density_scatter)
                 density_scatter = None
         else:
             density_scatter = None
+            density_after_dgrad = False
 
         # ---- colour branch (rgb_net + the two heads): data gradients w.r.t. [grid features | appearance code] first
+        # (compacted forward: the branch's activations hold the live rows only; the upstream gradients are brought
+        # into that order, rows behind a stop carry exact zeros anyway)
+        xn_col, n_col = xn, n
+        if ctx.compact:
+            live_idx, xn_col, rgb_c, np_c, sem_c, n_col = ctx.live
+            rgb_o, np_o, sem_o = rgb_c, np_c, sem_c
+
+            def to_live(t, cols):
+                if t is None:
+                    return None
+                out = torch.empty(n_col, cols, dtype=_f32, device=dev)
+                call("gather_rows", t.contiguous(), cols, cols, live_idx, n_col, out, cols)
+                return out
+            d_rgb, d_np, d_sem = to_live(d_rgb, 3), to_live(d_np, 3), to_live(d_sem, C)
+        n_full, n = n, n_col
         dfeat_rgb = None
         W_cols = 128 + E
         stages = []
@@ -452,11 +551,14 @@ class _FieldFn(Function):
             else:
                 g_sem = g_p
 
+        if density_after_dgrad and density_scatter is not None:
+            on_side(density_scatter)
+            density_scatter = None
         if dfeat_rgb is not None and need[9]:
             buf_c, g_rgbt = table_buffer(re, rgb_table)
 
             def colour_scatter():
-                call("grid_bwd_param", re.desc, xn, dfeat_rgb, W_cols, n, buf_c)
+                call("grid_bwd_param", re.desc, xn_col, dfeat_rgb, W_cols, n, buf_c)
                 cb = getattr(re, "on_grad_ready", None)
                 if cb is not None:
                     cb()
@@ -474,6 +576,7 @@ class _FieldFn(Function):
                 call("grid_bwd_input", re.desc, rgb_table, xn, dfeat_rgb, W_cols, n, g_x)
         for st in stages:
             st.weight_products()
+        n = n_full
 
         # ---- density head
         if d_sig is not None:
@@ -500,7 +603,7 @@ class _FieldFn(Function):
         # the norm-bound sums feed the optimizer's clip decision only: behind the weight products, where they fill the
         # wait for the scatters instead of sitting between the data gradient and the weight gradient (67 us there)
         if rgb_stage is not None:
-            _bound_note(model, rgb_stage, 0, 3, n)
+            _bound_note(model, rgb_stage, 0, 3, rgb_stage.n)
         if g_x is not None:
             g_x = g_x / span
         if forked:

@@ -313,7 +313,13 @@ def _render_rays_train(model, rays_o, rays_d, hits_t, **kwargs):
     for k, v in kwargs.items():
         if isinstance(v, torch.Tensor):
             kwargs[k] = torch.repeat_interleave(v[rays_a[:, 0]], rays_a[:, 2], 0, output_size=xyzs.shape[0])
-    sigmas, rgbs, normals_raw, normals_pred, sems = model(xyzs, dirs, **kwargs)
+    # the rays' segments go along: the field evaluates its colour branch only on the samples the compositor below
+    # will use (all up to a ray's early-termination point — same sigma, deltas and T_threshold, same decision)
+    model._live_ctx = (rays_a, results['deltas'], T_threshold)
+    try:
+        sigmas, rgbs, normals_raw, normals_pred, sems = model(xyzs, dirs, **kwargs)
+    finally:
+        model._live_ctx = None
     results['sigma'] = sigmas
     results['xyzs'] = xyzs
 

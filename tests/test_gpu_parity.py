@@ -2307,3 +2307,91 @@ def test_tcnn_frequency_and_network_with_input_encoding(ngp):
         assert okp.mean() > 0.999, okp.mean()
         if enc_cfg["otype"] == "HashGrid":
             assert gp[n_net:].abs().sum() > 0          # the table receives its share through the flat vector
+
+
+# ---------------------------------------------------------------------------- live samples: compacted colour branch
+def test_live_rows_match_compositor_stops(ngp, full_batch):
+    """ngp_live_rows keeps exactly the samples composite_train_fw uses: per ray all up to and including the sample at
+    which T <= T_threshold (vr_samples + 1 of them, or the whole segment), in ascending order; inv_idx is the inverse
+    list with -1 for the rest; gather / spread move row blocks there and back (zeros for the rest)."""
+    from ngp_amd._lib import call
+    b = full_batch
+    n, rays_a, deltas, ts = b["n"], b["rays_a"], b["deltas"], b["ts"]
+    nr = rays_a.shape[0]
+    g = torch.Generator(device=DEV).manual_seed(11)
+    sig = (torch.rand(n, device=DEV, generator=g) < 0.25).float() * torch.rand(n, device=DEV, generator=g) * 3000.0
+    rgbs = torch.rand(n, 3, device=DEV, generator=g)
+    zeros3, sems = torch.zeros(n, 3, device=DEV), torch.zeros(n, 7, device=DEV)
+    vr, op, dep, rgb, nrm, sem, ws = ngp.vren.composite_train_fw(sig, rgbs, zeros3, sems, deltas, ts, rays_a, 1e-4, 7)
+    want_live = torch.where(vr < rays_a[:, 2], vr + 1, rays_a[:, 2])         # stop sample included
+    assert int((want_live < rays_a[:, 2]).sum()) > 1000                      # the case is not trivial
+    offsets = torch.empty(nr, dtype=torch.int32, device=DEV)
+    live_idx = torch.full((n,), -7, dtype=torch.int32, device=DEV)
+    inv = torch.full((n,), -7, dtype=torch.int32, device=DEV)
+    n_live = torch.zeros(1, dtype=torch.int32, device=DEV)
+    xyz_c = torch.full((n, 3), 5.0, device=DEV)
+    call("live_rows", sig, deltas, rays_a, 1e-4, nr, offsets, live_idx, inv, n_live, b["xyzs"], xyz_c, None, None)
+    m = int(n_live[0])
+    assert m == int(want_live.sum())
+    assert torch.equal(offsets.long(), torch.cumsum(want_live, 0) - want_live)
+    k = torch.arange(n, device=DEV) - torch.repeat_interleave(rays_a[:, 1], rays_a[:, 2])
+    is_live = k < torch.repeat_interleave(want_live, rays_a[:, 2])
+    assert torch.equal(live_idx[:m].long(), torch.nonzero(is_live)[:, 0])
+    assert torch.equal(inv >= 0, is_live) and torch.equal(live_idx[:m].long()[inv[is_live].long()], live_idx[:m].long())
+    assert torch.all(ws[~is_live] == 0)                                     # nothing outside the list carries weight
+    assert torch.equal(xyz_c[:m], b["xyzs"][is_live]) and torch.all(xyz_c[m:] == 5.0)
+    c = torch.empty(m, 3, device=DEV)
+    call("gather_rows", rgbs, 3, 3, live_idx, m, c, 3)
+    assert torch.equal(c, rgbs[is_live])
+    back = torch.full((n, 3), 9.0, device=DEV)
+    call("spread_rows", c, 3, 3, inv, n, back, 3)
+    assert torch.equal(back, rgbs * is_live[:, None])
+    c7 = torch.rand(m, 7, device=DEV, generator=g)
+    b3, b3b, b7 = torch.full((n, 3), 9.0, device=DEV), torch.full((n, 3), 9.0, device=DEV), torch.full((n, 7), 9.0, device=DEV)
+    call("spread_rows3", c, 3, b3, c, 3, b3b, c7, 7, b7, inv, n)
+    assert torch.equal(b3, back) and torch.equal(b3b, back)
+    assert torch.equal(b7[is_live], c7) and torch.all(b7[~is_live] == 0)
+    # the image does not change when the colours behind the stops are dropped
+    vr2, op2, dep2, rgb2, *_ = ngp.vren.composite_train_fw(sig, back, zeros3, sems, deltas, ts, rays_a, 1e-4, 7)
+    assert torch.equal(rgb, rgb2) and torch.equal(op, op2) and torch.equal(vr, vr2)
+
+
+def test_compacted_colour_branch_matches_full(ngp, full_batch):
+    """render() with the colour branch on the live samples only (the default) against the same step with it on every
+    sample (NGP_NO_COMPACT): identical per-ray results — a row's bits do not depend on its position in the batch —
+    and gradients equal up to the summation order of the weight products and the atomics."""
+    from ngp_amd.rendering import render
+    b = full_batch
+    model = b["model"]
+    with torch.no_grad():   # a dense medium of varying density (sigma ~ 150 +- 100): most rays terminate early
+        model.xyz_net[2].bias.fill_(150.0)
+        model.xyz_net[2].weight.mul_(40.0)
+    o, d = b["o"][:2048].contiguous(), b["d"][:2048].contiguous()
+    gt = torch.rand(2048, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    outs = {}
+    for mode in (True, False):
+        ngp.networks._COMPACT = mode
+        try:
+            for p in model.parameters():
+                p.grad = None
+            torch.manual_seed(77)                                       # the marcher's per-ray jitter: the same twice
+            res = render(model, o, d, exp_step_factor=0.0)
+            loss = ((res["rgb"] - gt) ** 2).mean() + 1e-3 * (res["opacity"] ** 2).mean() + 1e-3 * res["Rp"].mean()
+            loss.backward()
+            outs[mode] = ({k: res[k].detach().clone() for k in ("rgb", "opacity", "depth", "ws", "normal_pred", "semantic",
+                                                                 "Ro", "Rp", "vr_samples")},
+                          {n_: p.grad.detach().clone() for n_, p in model.named_parameters() if p.grad is not None})
+        finally:
+            ngp.networks._COMPACT = True
+    (ra, ga), (rb, gb) = outs[True], outs[False]
+    n = int(res["total_samples"])
+    # vr_samples = sum over rays of the stop index (or the segment length): well below n when many rays stop early
+    assert int(ra["vr_samples"]) + 2048 < 0.9 * n, (int(ra["vr_samples"]), n)
+    for k in ra:
+        assert torch.equal(ra[k], rb[k]), k
+    assert set(ga) == set(gb)
+    for k in ga:
+        scale = float(gb[k].abs().max())
+        assert scale > 0, k
+        err = float((ga[k] - gb[k]).abs().max())
+        assert err <= 2e-5 * scale, (k, err, scale)
