@@ -1331,8 +1331,10 @@ def test_render_matches_reference_render_golden(ngp, golden, monkeypatch):
 G8_BAR, G10_BAR = 3e-4, 5e-5
 
 
-def test_training_step_matches_reference_golden(ngp, golden, monkeypatch):
-    """One whole training step against the G8 fixture — the reference's OWN render() -> NeRFLoss
+@pytest.mark.parametrize("compact", [False, True])
+def test_training_step_matches_reference_golden(ngp, golden, monkeypatch, compact):
+    """(compact: the same step with the colour branch on the live samples only, model.compact_dead_samples.)
+    One whole training step against the G8 fixture — the reference's OWN render() -> NeRFLoss
     (losses.py) -> sum of term means -> backward through its autograd Functions -> clip_grad_norm_(50)
     -> torch.optim.Adam(lr=1e-2, eps=1e-8).step(), run on the CPU (tinycudann = pure-torch stand-in,
     vren = C oracle).  Here: render() -> fused loss kernels -> backward -> NGPTrainer.optimizer_step()."""
@@ -1353,6 +1355,7 @@ def test_training_step_matches_reference_golden(ngp, golden, monkeypatch):
             named[k].copy_(T(g[k]))
         model.density_bitfield.copy_(T(g["density_bitfield"]))
     tr = NGPTrainer(model, lr=1e-2)                 # flat parameter / gradient / Adam-state buffers
+    model.compact_dead_samples = compact
     named = dict(model.named_parameters())
     o, d, gt = T(g["rays_o"]), T(g["rays_d"]), T(g["rgb_gt"])
     noise = T(g["noise"])
@@ -2357,8 +2360,8 @@ def test_live_rows_match_compositor_stops(ngp, full_batch):
 
 
 def test_compacted_colour_branch_matches_full(ngp, full_batch):
-    """render() with the colour branch on the live samples only (the default) against the same step with it on every
-    sample (NGP_NO_COMPACT): identical per-ray results — a row's bits do not depend on its position in the batch —
+    """render() with the colour branch on the live samples only (model.compact_dead_samples / NGP_COMPACT=1) against
+    the same step with it on every sample (the default): identical per-ray results — a row's bits do not depend on its position in the batch —
     and gradients equal up to the summation order of the weight products and the atomics."""
     from ngp_amd.rendering import render
     b = full_batch
@@ -2370,7 +2373,7 @@ def test_compacted_colour_branch_matches_full(ngp, full_batch):
     gt = torch.rand(2048, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
     outs = {}
     for mode in (True, False):
-        ngp.networks._COMPACT = mode
+        model.compact_dead_samples = mode
         try:
             for p in model.parameters():
                 p.grad = None
@@ -2382,7 +2385,7 @@ def test_compacted_colour_branch_matches_full(ngp, full_batch):
                                                                  "Ro", "Rp", "vr_samples")},
                           {n_: p.grad.detach().clone() for n_, p in model.named_parameters() if p.grad is not None})
         finally:
-            ngp.networks._COMPACT = True
+            model.compact_dead_samples = None
     (ra, ga), (rb, gb) = outs[True], outs[False]
     n = int(res["total_samples"])
     # vr_samples = sum over rays of the stop index (or the segment length): well below n when many rays stop early
