@@ -221,7 +221,7 @@ def test_empty_and_negative_batches_through_the_c_abi(ngp):
              "cols": 1, "grid_size": 128, "max_samples": 1024, "n_in": 16, "n_out": 1, "H": 32, "step": 1}
     # entry points whose empty call needs more than NULLs (an output scalar, a counter) are exercised on the GPU instead
     needs_outputs = {"ngp_density_grid_ema_threshold", "ngp_raymarching_train", "ngp_nerf_loss", "ngp_sumsq", "ngp_sumsq_if",
-                     "ngp_row_norm_sum"}
+                     "ngp_row_norm_sum", "ngp_live_rows"}
     checked = 0
     for name, (_, args) in _lib.PROTOS.items():
         names = [a for _, a in args]

@@ -2354,6 +2354,10 @@ def test_live_rows_match_compositor_stops(ngp, full_batch):
     call("spread_rows3", c, 3, b3, c, 3, b3b, c7, 7, b7, inv, n)
     assert torch.equal(b3, back) and torch.equal(b3b, back)
     assert torch.equal(b7[is_live], c7) and torch.all(b7[~is_live] == 0)
+    # an empty batch leaves a zero count
+    n_live.fill_(5)
+    call("live_rows", None, None, None, 1e-4, 0, None, None, None, n_live, None, None, None, None)
+    assert int(n_live[0]) == 0
     # the image does not change when the colours behind the stops are dropped
     vr2, op2, dep2, rgb2, *_ = ngp.vren.composite_train_fw(sig, back, zeros3, sems, deltas, ts, rays_a, 1e-4, 7)
     assert torch.equal(rgb, rgb2) and torch.equal(op, op2) and torch.equal(vr, vr2)
