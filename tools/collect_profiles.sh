@@ -22,7 +22,8 @@ python3 tools/prof_summary.py "$STATS" > gpurun_out/prof/${R}_bench_kernel_stats
 echo >> gpurun_out/prof/${R}_bench_kernel_stats.txt
 python3 tools/timeline.py "$TRACE" region 40 8 >> gpurun_out/prof/${R}_bench_kernel_stats.txt
 python3 tools/timeline.py "$TRACE" 12 > gpurun_out/prof/${R}_timeline.txt
-python3 tools/timeline.py "$TRACE" update > gpurun_out/prof/${R}_timeline_grid_update_step.txt
+python3 tools/timeline.py "$TRACE" update 10 > gpurun_out/prof/${R}_timeline_grid_update_step.txt
+python3 tools/timeline.py "$TRACE" steps 40 8 > gpurun_out/prof/${R}_step_walls.txt
 if [ "$1" != "nopmc" ]; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 4 > gpurun_out/prof/pmc_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 4 > gpurun_out/prof/pmc_write.log 2>&1

@@ -6,7 +6,11 @@ duration, queue and the idle gap on the device before it.  Also prints the busy/
 usage: timeline.py <kernel_trace.csv> [steps_from_end=3]
        timeline.py <kernel_trace.csv> region <K> [skip]   per-kernel time over K steps ending `skip` steps before the end
                                                           (bench.py: 40 timed steps, then 8 untimed ones with all kernels bracketed)
-       timeline.py <kernel_trace.csv> update         the last step that contains a density-grid update (packbits)
+       timeline.py <kernel_trace.csv> update [skip]  the last step that contains a density-grid update (packbits), at least
+                                                     `skip` steps before the end (bench.py's trailing steps are bracketed
+                                                     with events and the very last one follows a device synchronisation:
+                                                     skip 10 lands in the timed region)
+       timeline.py <kernel_trace.csv> steps <K> [skip]   wall time of each of K steps (update steps marked)
 """
 import csv
 import re
@@ -32,7 +36,26 @@ def is_mark(name):
     return any(m in name for m in STEP_MARKS)
 
 
-def main(path, back=3, with_update=False):
+def steps(path, k, skip=0):
+    rows = []
+    for r in csv.DictReader(open(path)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    marks = [i for i, r in enumerate(rows) if is_mark(r[2])]
+    plain, upd = [], []
+    for j in range(len(marks) - 1 - skip - k, len(marks) - 1 - skip):
+        lo, hi = marks[j], marks[j + 1]
+        wall = (rows[hi][0] - rows[lo][0]) / 1e3
+        u = any("packbits" in r[2] for r in rows[lo:hi])
+        (upd if u else plain).append(wall)
+        print(f"step {j - len(marks) + 1:4d}: {wall:8.1f} us{'   density-grid update' if u else ''}")
+    if plain and upd:
+        print(f"# plain steps {sum(plain)/len(plain):.1f} us (n={len(plain)}), update steps {sum(upd)/len(upd):.1f} us (n={len(upd)}): "
+              f"+{sum(upd)/len(upd) - sum(plain)/len(plain):.1f} us per update, "
+              f"+{(sum(upd)/len(upd) - sum(plain)/len(plain)) * len(upd) / (len(plain) + len(upd)):.1f} us per step")
+
+
+def main(path, back=3, with_update=False, skip=2):
     rows = []
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
@@ -41,7 +64,7 @@ def main(path, back=3, with_update=False):
     if len(adam) < back + 2:
         raise SystemExit("not enough steps in the trace")
     if with_update:
-        back = next(b for b in range(2, len(adam) - 1)
+        back = next(b for b in range(max(2, skip), len(adam) - 1)
                     if any("packbits" in r[2] for r in rows[adam[-b - 1]:adam[-b]]))
     lo, hi = adam[-back - 1], adam[-back]          # [optimizer of step k-1 ... optimizer of step k)
     step = rows[lo:hi]
@@ -85,6 +108,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[2] == "region":
         region(sys.argv[1], int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     elif len(sys.argv) > 2 and sys.argv[2] == "update":
-        main(sys.argv[1], with_update=True)
+        main(sys.argv[1], with_update=True, skip=int(sys.argv[3]) if len(sys.argv) > 3 else 2)
+    elif len(sys.argv) > 3 and sys.argv[2] == "steps":
+        steps(sys.argv[1], int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     else:
         main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3)
