@@ -1251,10 +1251,13 @@ int ngp_grid_bwd_param_scaled(const ngp_grid_desc* desc, const float* x, const f
                                    dL_dy, lddy, row_scale, n, dtable);
             return ngp_check_launch();
         }
-        const bool line = F == 8 && variant == 0 && lddy % 4 == 0 && ((uintptr_t)dL_dy & 15) == 0;
+        const bool line = F == 8 && variant == 0 && lddy % 4 == 0 && ((uintptr_t)dL_dy & 15) == 0 &&
+                          (uint64_t)desc->offsets[m.n_levels] * 8u < (1ull << 32);
 #else
-        // the two-phase kernel stages the gradient rows with 16-byte loads: row stride and base must allow them
-        const bool line = F == 8 && lddy % 4 == 0 && ((uintptr_t)dL_dy & 15) == 0;
+        // the two-phase kernel stages the gradient rows with 16-byte loads (row stride and base must allow them) and
+        // addresses the table with 32-bit element indices (below 2^32 floats: 2^29 rows)
+        const bool line = F == 8 && lddy % 4 == 0 && ((uintptr_t)dL_dy & 15) == 0 &&
+                          (uint64_t)desc->offsets[m.n_levels] * 8u < (1ull << 32);
 #endif
         if (line) {  // F = 8 (the reference's tables): accumulate per 64-byte line, two-phase kernel, 64-sample chunks
             constexpr int TCHUNK = 64;
