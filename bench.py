@@ -57,25 +57,70 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-march-ahead", action="store_true", help="march every batch inside its own step")
     ap.add_argument("--step-times", action="store_true", help="print the host time of every timed step to stderr")
+    ap.add_argument("--windows", type=int, default=5,
+                    help="further untimed-by-contract windows of --steps steps after the timed region (spread of the figure)")
+    ap.add_argument("--no-solo", action="store_true", help="skip the cache-cold solo replays of the captured launches")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--cpu-samples", type=int, default=64)
     return ap.parse_args()
 
 
-def cpu_baseline(model, scene, n_rays, n_samples):
-    """Times the CPU oracle's restatement of rendering_noCUDA.render (forward rendering of n_rays
-    rays x n_samples dense samples through the CPU hash-grid + MLP field) on the host cores."""
+def _host_cpu():
+    """(model string, physical cores, hardware threads) of the host from /proc/cpuinfo"""
+    model, cores, threads = "unknown", set(), 0
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                threads += 1
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+                cores.add((phys, core))
+    except OSError:
+        pass
+    try:
+        allowed = len(os.sched_getaffinity(0))      # a container may see fewer CPUs than the machine has
+    except (AttributeError, OSError):
+        allowed = threads or 1
+    n_phys = len(cores) or allowed
+    return model, min(n_phys, allowed), allowed
+
+
+def cpu_baseline(model, scene, n_rays, n_samples, crop=200):
+    """Times the CPU oracle's restatement of rendering_noCUDA.render (forward rendering of n_rays rays x n_samples
+    dense samples through the CPU hash-grid + MLP field) on the host cores, BASELINE.json configs[0]: rays drawn from
+    the centred `crop` x `crop` window of the training images, 1024 rays per batch.  Three ways: the restatement as
+    it is (OpenMP inside the C kernels, numpy glue serial) on every hardware thread; the same batch cut into ray
+    chunks rendered by one Python thread per PHYSICAL core (every C call single-threaded, BLAS limited to one
+    thread) — the figure reported as `value`; and one thread."""
+    import concurrent.futures
     import oracle
     from oracle import nocuda
     from oracle.field import CpuNGP
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:                                   # pragma: no cover
+        import contextlib
+        threadpool_limits = lambda **kw: contextlib.nullcontext()
     state = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()
              if k.endswith("params") or k.startswith("xyz_net")}
     field = CpuNGP(state, scale=model.scale)
     g = torch.Generator(device=scene.device).manual_seed(7)
-    img, pix = scene.sample_batch(n_rays, generator=g)
-    o, d = scene.rays(img, pix)
+    w, h = scene.img_wh
+    crop = min(crop, w, h)
+    img = torch.randint(scene.poses.shape[0], (n_rays,), device=scene.device, generator=g)
+    uu = torch.randint(crop, (n_rays,), device=scene.device, generator=g) + (w - crop) // 2
+    vv = torch.randint(crop, (n_rays,), device=scene.device, generator=g) + (h - crop) // 2
+    o, d = scene.rays(img, vv * w + uu)
     o, d = o.cpu().numpy(), d.cpu().numpy()
-    ref = nocuda.render([field, field], o, d, [n_samples])  # warm-up (page-in, OpenMP pool)
+    t_u = np.random.default_rng(20220806).random(n_rays, dtype=np.float32)   # the U[0,1) draws of rendering_noCUDA.py:139
+    ref = nocuda.render([field, field], o, d, [n_samples], t_rand_u=t_u)  # warm-up (page-in, OpenMP pool)
     # matched-PSNR check of the north star: the same rays AND sample depths through the HIP field +
     # compositor (render_dense) vs this CPU path, both scored against the scene's ground truth
     from ngp_amd.rendering import render_dense
@@ -89,41 +134,56 @@ def cpu_baseline(model, scene, n_rays, n_samples):
         return float(-10 * np.log10(np.mean((a - b) ** 2)))
     rgb_gpu = gpu["rgb"].cpu().numpy()
     hit = np.isfinite(ref["rgb0"]).all(-1)   # rays that miss the scene box have near == far -> 0/0 in
-    ref["rgb0"], rgb_gpu, gt = ref["rgb0"][hit], rgb_gpu[hit], gt[hit]   # rendering_noCUDA.py:146 (both paths)
-    match = {"psnr_cpu_path": _psnr(ref["rgb0"], gt), "psnr_hip_same_samples": _psnr(rgb_gpu, gt),
-             "psnr_hip_vs_cpu_path": _psnr(rgb_gpu, ref["rgb0"])}
+    rgb_ref, rgb_gpu, gt = ref["rgb0"][hit], rgb_gpu[hit], gt[hit]   # rendering_noCUDA.py:146 (both paths)
+    match = {"psnr_cpu_path": _psnr(rgb_ref, gt), "psnr_hip_same_samples": _psnr(rgb_gpu, gt),
+             "psnr_hip_vs_cpu_path": _psnr(rgb_gpu, rgb_ref)}
     match["psnr_delta"] = match["psnr_hip_same_samples"] - match["psnr_cpu_path"]
     match["rays_compared"] = int(hit.sum())
-    def timed(budget_s, max_reps):
+
+    def timed(fn, budget_s, max_reps):
         reps, t0 = 0, time.perf_counter()
         while True:
-            nocuda.render([field, field], o, d, [n_samples])
+            fn()
             reps += 1
             el = time.perf_counter() - t0
             if el > budget_s or reps >= max_reps:
                 return reps, el
+    cpu_model, phys, hw_threads = _host_cpu()
     all_threads = oracle.num_threads()
-    reps, el = timed(10.0, 50)
+    whole = lambda: nocuda.render([field, field], o, d, [n_samples], t_rand_u=t_u)
+    reps_omp, el_omp = timed(whole, 5.0, 50)
+    # one Python thread per physical core, each rendering its own chunk of rays with single-threaded C kernels
+    workers = max(1, phys)
+    parts = [p for p in np.array_split(np.arange(n_rays), workers * 2) if len(p)]
+
+    def init_worker():
+        oracle.set_num_threads(1)             # OpenMP's thread count is per calling thread
+
+    def render_part(idx):
+        return nocuda.render([field, field], o[idx], d[idx], [n_samples], t_rand_u=t_u[idx])["rgb0"]
+    with threadpool_limits(limits=1), \
+            concurrent.futures.ThreadPoolExecutor(workers, initializer=init_worker) as pool:
+        chunked = lambda: list(pool.map(render_part, parts))
+        out = np.concatenate(chunked())       # warm-up, and the chunks must reproduce the whole batch
+        same = bool(np.allclose(out[hit], rgb_ref, rtol=1e-5, atol=1e-6))
+        reps, el = timed(chunked, 10.0, 200)
     # the same sample on ONE thread as well (a scalar port's figure), a few seconds of it
     oracle.set_num_threads(1)
-    reps1, el1 = timed(8.0, 3)
+    with threadpool_limits(limits=1):
+        reps1, el1 = timed(whole, 6.0, 3)
     oracle.set_num_threads(all_threads)
-    cpu_model = "unknown"
-    try:
-        for ln in open("/proc/cpuinfo"):
-            if ln.startswith("model name"):
-                cpu_model = ln.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
     return {
-        "value": n_rays * reps / el, "unit": "rays/s", "cores": all_threads, "kind": "port",
+        "value": n_rays * reps / el, "unit": "rays/s", "cores": workers, "kind": "port",
+        "threads": workers, "physical_cores": phys, "hardware_threads": hw_threads,
         "samples_per_s": n_rays * n_samples * reps / el,
-        "sample": f"{reps}x forward render of {n_rays} rays x {n_samples} dense samples "
-                  f"(oracle restatement of rendering_noCUDA.render + CPU hash-grid/MLP field, {el:.1f}s)",
+        "sample": f"{reps}x forward render of {n_rays} rays (centred {crop}x{crop} crop, configs[0]) x {n_samples} dense samples "
+                  f"(oracle restatement of rendering_noCUDA.render + CPU hash-grid/MLP field) as {len(parts)} ray chunks on "
+                  f"{workers} threads = one per physical core, {el:.1f}s; chunks reproduce the whole batch: {same}",
         "cpu_model": cpu_model,
+        "openmp_all_threads": {"value": n_rays * reps_omp / el_omp, "unit": "rays/s", "threads": all_threads,
+                               "sample": f"{reps_omp}x the same batch in one piece, OpenMP inside the C kernels only ({el_omp:.1f}s)"},
         "one_thread": {"value": n_rays * reps1 / el1, "unit": "rays/s", "cores": 1,
-                       "sample": f"{reps1}x the same render on 1 OpenMP thread ({el1:.1f}s)"},
+                       "sample": f"{reps1}x the same render on 1 thread ({el1:.1f}s)"},
         "parity": match,
     }
 
@@ -235,16 +295,14 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    # HIP events around EVERY kernel of the step cost 2.4 % of the step (measured A/B): inside the timed region
-    # only the dominant kernel is bracketed (the roofline's live measurement); the other kernels' figures come
-    # from a short untimed pass right after it
-    # the two candidates for "dominant kernel" (the colour/density scatters and the clip+Adam sweep: 4 launches of
-    # ~60 per step) are both bracketed live; whichever took more device time per step in the timed region is the
-    # `roofline` kernel, the other one is reported beside it
-    LIVE = ("grid_bwd_param", "adam_step")   # "grid_bwd_param" collects both scatter entry points, see below
-    prof_keys = ("grid_fwd", "grid_bwd_input", "linear_fwd", "linear_bwd_input",
-                 "linear_bwd_weight", "mlp_bwd_input", "mlp_bwd_weight", "mlp2_fwd", "sumsq")
+    # HIP events around EVERY library call of the step cost 2.4 % of the step (measured A/B): inside the timed region only
+    # the candidates for "dominant kernel" are bracketed — the two hash-grid gathers (3 launches per step), the table
+    # scatter (2) and the clip + Adam sweep (2): 7 of ~55 launches, 14 events per step.  Whichever took most device time per
+    # step in the timed region is the `roofline` kernel; the MLP products' figures come from a short untimed pass after it.
+    LIVE = ("grid_fwd", "grid_bwd_input", "grid_bwd_param", "adam_step")   # "grid_bwd_param" collects both scatter entry points
+    prof_keys = ("linear_fwd", "linear_bwd_input", "linear_bwd_weight", "mlp_bwd_input", "mlp_bwd_weight", "mlp2_fwd", "sumsq")
     _lib.PROFILE = {k: [] for k in LIVE + SCATTER_CALLS}
+    step_at_start = trainer.global_step
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tot_samples, last = run(args.steps, args.warmup, False)
@@ -253,40 +311,60 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof_live, _lib.PROFILE = _lib.PROFILE, {k: [] for k in prof_keys}
+    updates_in_region = sum(1 for g in range(step_at_start, step_at_start + args.steps) if g % trainer.update_interval == 0)
     post_steps = min(8, args.steps)
     trainer.buckets.trace = []
     run(post_steps, args.warmup + args.steps, False)
     torch.cuda.synchronize()
     comm_trace, trainer.buckets.trace = trainer.buckets.trace, None
-    prof, _lib.PROFILE = _lib.PROFILE, None      # the replays below are timed on their own
-    # SOLO rates: one more untimed step with the arguments of the scatter / MLP launches captured, then every one of
-    # them replayed alone on an idle device (3 repetitions).  In the step these kernels share the memory system with
-    # whatever runs on the other streams (the two scatters run beside the MLP weight products by design), so their
-    # in-step durations say how the schedule shares the device, the solo ones what the kernel itself does.
+    prof, _lib.PROFILE = _lib.PROFILE, None      # the windows and replays below are timed on their own
+    # the timed region is short (K steps of ~4 ms): further windows of the same K steps, each between two device
+    # synchronisations, say how the region's figure sits in the run-to-run spread (reported, never the `value`)
+    windows = []
+    pos = args.warmup + args.steps + post_steps
+    for _ in range(args.windows):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tw = time.perf_counter()
+        run(args.steps, pos, False)
+        torch.cuda.synchronize()
+        windows.append((time.perf_counter() - tw) / args.steps * 1e3)
+        pos += args.steps
+    # SOLO rates: one more untimed step with the arguments of the gather / scatter / MLP launches captured, then every one
+    # of them replayed alone on an idle device.  In the step these kernels share the memory system with whatever runs on
+    # the other streams (the scatters run beside the MLP weight products, the density gather beside the Adam sweep), so
+    # their in-step durations say how the schedule shares the device, the solo ones what the kernel itself does.  Every
+    # repetition is timed on its own behind a 1 GiB fill: tables (174 / 588 MB) and activations start in HBM, not in the
+    # 256 MiB Infinity Cache (back-to-back replays of one launch read above the HBM peak).
     solo_keys = SCATTER_CALLS + ("mlp_bwd_input", "mlp_bwd_weight", "mlp2_fwd", "grid_fwd", "grid_bwd_input")
     solo = {}
-    if world == 1:
+    if world == 1 and not args.no_solo:
         extra = 0
         if trainer.global_step % trainer.update_interval == 0:   # not a step that starts with an occupancy update
-            run(1, args.warmup + args.steps + post_steps, False)
+            run(1, pos, False)
             extra = 1
         _lib.CAPTURE = {k: [] for k in solo_keys}
-        run(1, args.warmup + args.steps + post_steps + extra, False)
+        run(1, pos + extra, False)
         trainer.wait()
         torch.cuda.synchronize()
         cap, _lib.CAPTURE = _lib.CAPTURE, None
+        flush = torch.empty(1 << 28, dtype=torch.float32, device=dev)   # 1 GiB
         for name, calls in cap.items():
             for a in calls:
                 _lib.call(name, *a)               # once untimed (code / TLB warm)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize()
-                e0.record()
+                reps = []
                 for _ in range(3):
+                    flush.fill_(1.0)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                     _lib.call(name, *a)
-                e1.record()
-                torch.cuda.synchronize()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    reps.append(e0.elapsed_time(e1))
                 key = "grid_bwd_param" if name in SCATTER_CALLS else name
-                solo.setdefault(key, []).append((e0.elapsed_time(e1) / 3, tuple(x for x in a if isinstance(x, int))))
+                solo.setdefault(key, []).append((sorted(reps)[1], tuple(x for x in a if isinstance(x, int))))
+        del flush
     # multi-GPU readiness: what every rank sent through the backend per step, and behind which HIP stream
     main_stream = torch.cuda.current_stream().cuda_stream
     per_step = {}
@@ -376,14 +454,18 @@ def main():
             kern[name]["steps"] = steps_of(name)
             kern[name]["ms_per_step"] = kern[name]["total_ms"] / kern[name]["steps"]
         grid_names = [k for k in kern if k.startswith("grid")]
-        # dominant kernel = most device time per step among the live-bracketed candidates (timed region)
-        dom = max(LIVE, key=lambda k: kern[k]["ms_per_step"] if k in kern else 0.0)
+        # dominant kernel = most device time per step among the kernels bracketed INSIDE the timed region (the gathers,
+        # the scatter, the clip + Adam sweep); `heaviest_kernel_per_step` is the same maximum over every kernel measured
+        # (the MLP products come from the post-region pass) — the two must agree, and the line says so
+        live = [k for k in LIVE if k in kern]
+        dom = max(live, key=lambda k: kern[k]["ms_per_step"])
         heaviest = max(kern, key=lambda k: kern[k]["ms_per_step"])
         # HBM traffic per launch from the committed rocprofv3 --pmc passes over this same command
-        # (profiles/r02_pmc_traffic.json, tools/pmc_traffic.py): WRITE_SIZE is exact for fp32 atomics and 16-B
-        # streaming stores; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B).
+        # (profiles/rNN_pmc_traffic.json, tools/pmc_traffic.py), ONE definition everywhere: 2 x FETCH_SIZE + WRITE_SIZE
+        # (MI355X_MICROARCH.md §HBM: gfx950 tallies 128-byte read requests at 64 bytes; WRITE_SIZE is exact for fp32
+        # atomics and 16-byte streaming stores).
         pmc_all = {}
-        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc_all = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 pmc_all["_file"] = fn
@@ -401,12 +483,23 @@ def main():
                 return (2 * pmc["fetch_bytes_per_param"] + pmc["write_bytes_per_param"]) * kern[name]["avg_params"]
             return None
 
-        for name in grid_names:
-            pmc = pmc_all.get(name)
-            if pmc and "fetch_bytes_per_sample" in pmc:
-                b_ = (pmc["fetch_bytes_per_sample"] + pmc["write_bytes_per_sample"]) * kern[name]["avg_samples"]
+        for name in grid_names + ["adam_step"]:
+            b_ = traffic_of(name) if name in kern else None
+            if b_:
                 kern[name]["hbm_bytes_pmc"] = b_
                 kern[name]["hbm_GBps_pmc"] = b_ / (kern[name]["avg_ms"] * 1e-3) / 1e9
+
+        NOTES = {
+            "grid_fwd": "hash-grid gather, both tables: 16 levels x 8 corners x 32 B read + 512 B written per sample (SURVEY §8(d)); "
+                        "a run of consecutive samples in one cell loads its corners once (run-leader kernel), and what binds the "
+                        "kernel is the number of 64-byte L1 misses a CU keeps in flight (profiles/r03_gather_pmc.txt), not HBM bytes",
+            "grid_bwd_input": "the same gather on the density table with the upstream gradient (4096 + 512 + 12 B per sample)",
+            "grid_bwd_param": "4096 B of fp32 atomic adds + 512 B read per sample; the binding resource is the memory-side "
+                              "atomic REQUEST rate (one request per 64-byte line a wave-instruction touches, 20 G/s "
+                              "measured: profiles/r02_atomic_shapes.txt), see `atomic_requests`; line-aligned run merging + "
+                              "zero skipping cut the real traffic to `traffic` bytes per launch",
+            "adam_step": "clip + Adam sweep over all 200 M parameters: p, g, m, v read, p, m, v written",
+        }
 
         def roof(name):
             k = kern[name]
@@ -414,28 +507,29 @@ def main():
                  "frac": k["GBps"] / HBM_PEAK_GBS, "traffic": traffic_of(name), "traffic_source": pmc_all.get("_file"),
                  "avg_launch_ms": k["avg_ms"], "ms_per_step": k["ms_per_step"], "launches": k["launches"],
                  "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
-                 "formula": "achieved = sum over the timed region's launches of algorithmic bytes / sum of their HIP-event durations"}
+                 "formula": "achieved = sum over the timed region's launches of algorithmic bytes / sum of their HIP-event durations",
+                 "note": NOTES[name]}
             if "solo_GBps" in k:
-                r["solo"] = {"achieved": k["solo_GBps"], "frac": k["solo_GBps"] / HBM_PEAK_GBS, "avg_launch_ms": k["solo_avg_ms"],
-                             "note": "the same launches (arguments captured from one more step) replayed alone on an idle device"}
-            if name == "grid_bwd_param":
+                fr = k["solo_GBps"] / HBM_PEAK_GBS
+                r["solo"] = {"achieved": k["solo_GBps"], "frac": fr, "avg_launch_ms": k["solo_avg_ms"],
+                             "note": "the same launches (arguments captured from one more step) replayed alone, each repetition "
+                                     "behind a 1 GiB fill (tables and activations start in HBM, not in the Infinity Cache)"}
+                if fr > 1.0:     # algorithmic bytes above the HBM peak = the bytes did not come from HBM: not a roofline figure
+                    r["solo"] = {"invalid": "algorithmic rate above the HBM peak (cache-resident operands)", "achieved": k["solo_GBps"]}
+            if name == "adam_step":
+                r["algorithmic_bytes_per_param"] = ADAM_BYTES_PER_PARAM
+            else:
                 r["algorithmic_bytes_per_sample"] = BYTES_PER_SAMPLE[name]
+            if name == "grid_bwd_param":
                 req = pmc_all.get(name, {}).get("atomic_requests_per_sample")
                 if req:
                     rate = req * k["avg_samples"] / (k["avg_ms"] * 1e-3)
                     r["atomic_requests"] = {"per_sample": req, "per_launch": req * k["avg_samples"], "rate_per_s": rate,
                                             "peak_per_s": ATOMIC_REQ_PEAK, "frac": rate / ATOMIC_REQ_PEAK}
-                r["note"] = ("4096 B of fp32 atomic adds + 512 B read per sample; the binding resource is the memory-side "
-                             "atomic REQUEST rate (one request per 64-byte line a wave-instruction touches, 20 G/s "
-                             "measured: profiles/r02_atomic_shapes.txt), see `atomic_requests`; line-aligned run merging + "
-                             "zero skipping cut the real traffic to `traffic` bytes per launch")
-            else:
-                r["algorithmic_bytes_per_param"] = ADAM_BYTES_PER_PARAM
-                r["note"] = "clip + Adam sweep over all 200 M parameters: p, g, m, v read, p, m, v written"
             return r
         roofline = roof(dom)
         roofline["heaviest_kernel_per_step"] = heaviest
-        roofline["other_candidate"] = roof([k for k in LIVE if k != dom and k in kern][0]) if len([k for k in LIVE if k in kern]) > 1 else None
+        roofline["other_candidates"] = [roof(k) for k in sorted(live, key=lambda k: -kern[k]["ms_per_step"]) if k != dom]
         # MFMA utilisation of the MLP products against the dense f32 MFMA peak of gfx950
         lin = [kern[k] for k in kern if k.startswith("linear") or k.startswith("mlp")]
         mlp = None
@@ -456,6 +550,9 @@ def main():
             "metric": "train rays/sec", "value": rays_total / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step_median_of_windows": (sorted(windows)[len(windows) // 2] if windows else None),
+            "ms_per_step_windows": [round(v, 4) for v in windows],
+            "grid_update_steps_in_timed_region": updates_in_region,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "samples_per_s": total_samples / elapsed,
             "samples_per_ray": total_samples / rays_total,

@@ -142,6 +142,489 @@ __global__ void __launch_bounds__(256) grid_fwd_kernel(GridMeta meta, const floa
     *reinterpret_cast<vec_t*>(y + sample * ldy + level * F + sub * V) = out;
 }
 
+// ------------------------------------------------------------------ ray-coherent tile gathers (H1, H3; F = 8)
+// Samples arrive in ray order (the marcher's), and consecutive samples of a ray stand in the same cell on the
+// coarse levels (step sqrt(3)/1024 against cells of 1/16 .. 1/1024): the item-per-(sample, level) kernel above
+// fetches those rows again for every sample.  Here a WAVE owns S = 32 CONSECUTIVE samples x 4 levels (the four
+// waves of a workgroup cover the 16 levels of one sample tile), and per level
+//   phase 1  lane = (sample, half row): cell of the sample; a lane whose cell differs from the previous sample's
+//            opens a run; ballot + popcount number the runs, the run leaders write their cell into a list (LDS);
+//   phase 2  lane = (unique cell, corner, half row): ONE 16-byte load per (unique cell, corner, half) instead of
+//            one per (sample, corner, half), committed to a wave-private LDS image [cell][half][corner] (padded:
+//            conflict-free for the reads of phase 3);
+//   phase 3  lane = (sample, half row): the sample's eight corner pieces come back from LDS (lanes of one run read
+//            the same address: broadcast), trilinear blend in the forward kernel's operation order (bit-identical).
+// The loads of level i+1 are in flight under phase 3 of level i.  The tile's outputs (32 samples x 4 levels x 8
+// floats) leave through the same LDS image transposed, so that every store instruction writes whole 128-byte
+// segments of the (n, L*F) rows.
+namespace tile {
+constexpr int F = 8;
+constexpr int LV = 4;                 // levels per wave
+constexpr int S = 32;                 // samples per wave
+constexpr int CELL = 68;              // dwords per staged cell: [half 2][corner 8][4] + 4 (bank spread, see phase 3)
+constexpr int LIST = 4 * S;           // dwords per cell list: (gx, gy, gz, -) per run
+constexpr int WAVE_LDS = 2 * LIST + S * CELL;
+
+struct Run {
+    float w0, w1, w2;
+    uint32_t u;                       // index of the lane's run (= unique cell) among the wave's
+    uint32_t U;                       // number of runs, wave-uniform
+};
+
+__device__ __forceinline__ Run phase1(const LevelInfo& li, float px, float py, float pz, int lane, uint32_t* list)
+{
+    const float p0 = fmaf(li.scale, px, 0.5f), p1 = fmaf(li.scale, py, 0.5f), p2 = fmaf(li.scale, pz, 0.5f);
+    const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+    const int g0 = (int)f0, g1 = (int)f1, g2 = (int)f2;
+    const int q0 = __shfl_up(g0, 2), q1 = __shfl_up(g1, 2), q2 = __shfl_up(g2, 2);
+    const bool lead = !(lane & 1) && (lane < 2 || g0 != q0 || g1 != q1 || g2 != q2);
+    const unsigned long long m = __ballot(lead);
+    Run r;
+    r.w0 = p0 - f0; r.w1 = p1 - f1; r.w2 = p2 - f2;
+    r.u = (uint32_t)__popcll(m & ((2ull << lane) - 1ull)) - 1u;   // leaders at or below this lane (lane 63: mask = ~0)
+    r.U = (uint32_t)__popcll(m);
+    if (lead) *reinterpret_cast<uint4*>(list + 4 * r.u) = make_uint4((uint32_t)g0, (uint32_t)g1, (uint32_t)g2, 0u);
+    return r;
+}
+
+// row of a corner for the two kinds of level the tile kernels take (the launcher sends layouts with a hashed level whose
+// size is no power of two, or tables of 4 GiB and more, to the item-per-(sample, level) kernels): byte offset into the table
+template <bool HASHED>
+__device__ __forceinline__ uint32_t row_offset(const LevelInfo& li, uint32_t x, uint32_t y, uint32_t z)
+{
+    uint32_t idx;
+    if (HASHED)
+        idx = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & (li.size - 1u);
+    else {
+        idx = x + li.res * (y + li.res * z);        // < 2 res^3 <= 2 size: one conditional subtraction is the modulo
+        idx -= idx >= li.size ? li.size : 0u;
+    }
+    return (li.offset + idx) * (uint32_t)(F * sizeof(float));
+}
+
+// phase 2a: the loads of one level (at most 8 per lane: 32 cells x 16 pieces / 64 lanes), into registers
+template <bool HASHED>
+__device__ __forceinline__ void issue_impl(const LevelInfo& li, const char* __restrict__ table, const uint32_t* list,
+                                           uint32_t U, int lane, float4 (&R)[8])
+{
+    const uint32_t cq = (uint32_t)lane >> 4, corner = ((uint32_t)lane >> 1) & 7u, half = (uint32_t)lane & 1u;
+    const uint32_t cx = corner & 1u, cy = (corner >> 1) & 1u, cz = corner >> 2;
+    const uint32_t* mine = list + 4 * cq;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // (a conditional store into R[it] would send R to scratch)
+        if ((uint32_t)(it * 4) < U) {                       // wave-uniform
+            if (it * 4 + cq < U) {
+                const uint32_t gx = mine[16 * it], gy = mine[16 * it + 1], gz = mine[16 * it + 2];
+                const uint32_t off = row_offset<HASHED>(li, gx + cx, gy + cy, gz + cz) + half * 16u;
+                v = *reinterpret_cast<const float4*>(table + off);
+            }
+        }
+        R[it] = v;
+    }
+}
+
+__device__ __forceinline__ void issue(const LevelInfo& li, const float* __restrict__ table, const uint32_t* list,
+                                      uint32_t U, int lane, float4 (&R)[8])
+{
+    if (li.flags & 1u) issue_impl<true>(li, reinterpret_cast<const char*>(table), list, U, lane, R);
+    else issue_impl<false>(li, reinterpret_cast<const char*>(table), list, U, lane, R);
+}
+
+// phase 2b: registers -> LDS image
+__device__ __forceinline__ void commit(float* cells, uint32_t U, int lane, const float4 (&R)[8])
+{
+    const uint32_t cq = (uint32_t)lane >> 4, corner = ((uint32_t)lane >> 1) & 7u, half = (uint32_t)lane & 1u;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        if ((uint32_t)(it * 4) < U) {
+            const uint32_t c = it * 4 + cq;
+            if (c < U) *reinterpret_cast<float4*>(cells + c * CELL + half * 32 + corner * 4) = R[it];
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+}  // namespace tile
+
+__global__ void __launch_bounds__(256, 4) grid_fwd_tile_kernel(GridMeta meta, const float* __restrict__ table,
+                                                            const float* __restrict__ x, int64_t n,
+                                                            float* __restrict__ y, int64_t ldy)
+{
+    using namespace tile;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][WAVE_LDS];
+    uint32_t* W = lds[threadIdx.x >> 6];
+    float* cells = reinterpret_cast<float*>(W + 2 * LIST);
+    const uint32_t L = meta.n_levels;
+    const uint32_t wpc = (L + LV - 1) / LV;                 // waves per sample tile
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t chunk = wave_global / wpc;
+    const uint32_t lg = (uint32_t)(wave_global - chunk * wpc);   // scalar: the level records come by s_load
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = chunk * S;
+    if (s0 >= n) return;
+    const int j = lane >> 1, half = lane & 1;
+    const int64_t sj = s0 + j < n ? s0 + j : n - 1;         // tail lanes repeat the last sample (same run, no extra loads)
+    const float px = x[3 * sj], py = x[3 * sj + 1], pz = x[3 * sj + 2];
+    const uint32_t nlv = L - lg * LV < (uint32_t)LV ? L - lg * LV : (uint32_t)LV;
+
+    float4 R[8];
+    float out[LV][4];
+    LevelInfo li = level_info(meta, lg * LV);
+    Run cur = phase1(li, px, py, pz, lane, W);
+    wave_sync();
+    issue(li, table, W, cur.U, lane, R);
+#pragma unroll
+    for (int i = 0; i < LV; i++) {
+        if ((uint32_t)i < nlv) {                            // wave-uniform
+            commit(cells, cur.U, lane, R);
+            Run nxt = cur;
+            if ((uint32_t)(i + 1) < nlv) {
+                li = level_info(meta, lg * LV + i + 1);
+                uint32_t* list = W + ((i + 1) & 1) * LIST;
+                nxt = phase1(li, px, py, pz, lane, list);
+                wave_sync();
+                issue(li, table, list, nxt.U, lane, R);
+            } else
+                wave_sync();
+            const float* cb = cells + cur.u * CELL + half * 32;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float4 v = *reinterpret_cast<const float4*>(cb + k * 4);
+                const float wt = ((k & 1) ? cur.w0 : 1 - cur.w0) * ((k & 2) ? cur.w1 : 1 - cur.w1) * ((k & 4) ? cur.w2 : 1 - cur.w2);
+                vec_fma<4>(acc, wt, v);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) out[i][q] = acc[q];
+            cur = nxt;
+            wave_sync();                                    // phase 3's reads before the next commit
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) out[i][q] = 0.0f;
+        }
+    }
+    // transposition: lane (sample j, half) -> lane (sample it*8 + lane/8, 16-byte piece lane%8 of the 128 bytes)
+#pragma unroll
+    for (int i = 0; i < LV; i++)
+        *reinterpret_cast<float4*>(cells + j * 32 + i * 8 + half * 4) = make_float4(out[i][0], out[i][1], out[i][2], out[i][3]);
+    wave_sync();
+    const int piece = lane & 7;
+    if ((lg * LV + (piece >> 1)) < L) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int js = it * 8 + (lane >> 3);
+            if (s0 + js < n)
+                *reinterpret_cast<float4*>(y + (s0 + js) * ldy + lg * (LV * F) + piece * 4) =
+                    *reinterpret_cast<const float4*>(cells + js * 32 + piece * 4);
+        }
+    }
+}
+
+// input gradient on the same tiles: phase 3 forms the three partial derivatives from the staged corners, the four
+// level groups of a sample tile meet in LDS and the tile's (32, 3) block of dL_dx leaves as one contiguous store.
+#ifndef NGP_TILE_BI_WAVES
+#define NGP_TILE_BI_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, NGP_TILE_BI_WAVES) grid_bwd_input_tile_kernel(GridMeta meta, const float* __restrict__ table,
+                                                                  const float* __restrict__ x,
+                                                                  const float* __restrict__ dL_dy, int64_t lddy,
+                                                                  int64_t n, float* __restrict__ dL_dx)
+{
+    using namespace tile;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][WAVE_LDS];
+    uint32_t* W = lds[threadIdx.x >> 6];
+    float* cells = reinterpret_cast<float*>(W + 2 * LIST);
+    float* red = reinterpret_cast<float*>(W);               // the wave's (32, 3) partial sums, over its dead cell lists
+    const uint32_t L = meta.n_levels;
+    const uint32_t wpc = (L + LV - 1) / LV;                 // 1, 2 or 4 (checked by the launcher)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t chunk = wave_global / wpc;
+    const uint32_t lg = (uint32_t)(wave_global - chunk * wpc);
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = chunk * S;
+    const bool active = s0 < n;                             // wave-uniform; no early exit: the block meets at a barrier
+    const int j = lane >> 1, half = lane & 1;
+    float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+    if (active) {
+        const int64_t sj = s0 + j < n ? s0 + j : n - 1;
+        const float px = x[3 * sj], py = x[3 * sj + 1], pz = x[3 * sj + 2];
+        const uint32_t nlv = L - lg * LV < (uint32_t)LV ? L - lg * LV : (uint32_t)LV;
+        // the tile's upstream gradients: whole 128-byte segments in, (sample, half) pieces out of LDS
+        float4 go[LV];
+        {
+            const int piece = lane & 7;
+            const bool have = (lg * LV + (piece >> 1)) < L;
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int js = it * 8 + (lane >> 3);
+                const int64_t sg = s0 + js < n ? s0 + js : n - 1;
+                const float4 v = have ? *reinterpret_cast<const float4*>(dL_dy + sg * lddy + lg * (LV * F) + piece * 4)
+                                      : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                *reinterpret_cast<float4*>(cells + js * 32 + piece * 4) = v;
+            }
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < LV; i++) go[i] = *reinterpret_cast<const float4*>(cells + j * 32 + i * 8 + half * 4);
+            wave_sync();
+        }
+        float4 R[8];
+        LevelInfo li = level_info(meta, lg * LV);
+        Run cur = phase1(li, px, py, pz, lane, W);
+        wave_sync();
+        issue(li, table, W, cur.U, lane, R);
+#pragma unroll
+        for (int i = 0; i < LV; i++) {
+            if ((uint32_t)i < nlv) {
+                const float scale = li.scale;
+                commit(cells, cur.U, lane, R);
+                Run nxt = cur;
+                if ((uint32_t)(i + 1) < nlv) {
+                    li = level_info(meta, lg * LV + i + 1);
+                    uint32_t* list = W + ((i + 1) & 1) * LIST;
+                    nxt = phase1(li, px, py, pz, lane, list);
+                    wave_sync();
+                    issue(li, table, list, nxt.U, lane, R);
+                } else
+                    wave_sync();
+                const float* cb = cells + cur.u * CELL + half * 32;
+                const float g4[4] = {go[i].x, go[i].y, go[i].z, go[i].w};
+                const float wx0 = 1 - cur.w0, wx1 = cur.w0, wy0 = 1 - cur.w1, wy1 = cur.w1, wz0 = 1 - cur.w2, wz1 = cur.w2;
+                // one z plane of corners at a time (16 registers of corner data instead of 32): d/dx and d/dy inside the
+                // plane, d/dz as the plane z1 arrives and replaces z0 corner by corner
+                float4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const float4*>(cb + k * 4);
+                float dx = wz0 * (wy0 * vec_dot<4>(g4, v[1], v[0]) + wy1 * vec_dot<4>(g4, v[3], v[2]));
+                float dy = wz0 * (wx0 * vec_dot<4>(g4, v[2], v[0]) + wx1 * vec_dot<4>(g4, v[3], v[1]));
+                float dz = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float4 t = *reinterpret_cast<const float4*>(cb + (k + 4) * 4);
+                    dz = fmaf(((k & 1) ? wx1 : wx0) * ((k & 2) ? wy1 : wy0), vec_dot<4>(g4, t, v[k]), dz);
+                    v[k] = t;
+                }
+                dx = fmaf(wz1, wy0 * vec_dot<4>(g4, v[1], v[0]) + wy1 * vec_dot<4>(g4, v[3], v[2]), dx);
+                dy = fmaf(wz1, wx0 * vec_dot<4>(g4, v[2], v[0]) + wx1 * vec_dot<4>(g4, v[3], v[1]), dy);
+                gx = fmaf(dx, scale, gx); gy = fmaf(dy, scale, gy); gz = fmaf(dz, scale, gz);
+                cur = nxt;
+                wave_sync();
+            }
+        }
+        gx += __shfl_xor(gx, 1); gy += __shfl_xor(gy, 1); gz += __shfl_xor(gz, 1);
+        if (!half) { red[3 * j] = gx; red[3 * j + 1] = gy; red[3 * j + 2] = gz; }
+    }
+    __syncthreads();
+    // thread t: tile t / 96 of the block, float t % 96 of its (32, 3) block
+    const int tiles = 4 / (int)wpc;
+    for (int t = threadIdx.x; t < tiles * S * 3; t += 256) {
+        const int tl = t / (S * 3), r = t - tl * (S * 3);
+        const int64_t c0 = ((int64_t)blockIdx.x * 4 + tl * (int)wpc) / wpc * S;   // first sample of that tile
+        if (c0 < n && c0 + r / 3 < n) {
+            float sum = 0.0f;
+            for (uint32_t w = 0; w < wpc; w++) sum += reinterpret_cast<const float*>(lds[tl * wpc + w])[r];
+            dL_dx[3 * c0 + r] = sum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ run-leader gathers (H1, H3; F = 8), no cell staging
+// Same tiles (a wave = 32 consecutive samples x 4 levels, lane = (sample, half row)), but the unique cells are not
+// compacted: only the lanes that OPEN a run (first sample of a run of equal cells) load their eight corner pieces,
+// and the other lanes of the run fetch them from the leader's registers with ds_bpermute (32 dwords per level; none
+// when every sample opens its own run, the usual case on the finest levels).  No LDS image of the cells, so the
+// kernel keeps 8 waves per SIMD and as many loads in flight as the item-per-(sample, level) kernel, with the
+// duplicate requests of a run removed.
+namespace run {
+constexpr int F = 8, LV = 4, S = 32;
+
+struct Lead {
+    float w0, w1, w2;
+    int g0, g1, g2;
+    bool lead;                         // this lane's sample opens a run
+    int src;                           // lane that holds the lane's corner pieces (the run leader's lane of the same half)
+    bool all;                          // every sample opens its own run (wave-uniform)
+};
+
+__device__ __forceinline__ Lead phase1(float scale, float px, float py, float pz, int lane)
+{
+    Lead r;
+    const float p0 = fmaf(scale, px, 0.5f), p1 = fmaf(scale, py, 0.5f), p2 = fmaf(scale, pz, 0.5f);
+    const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+    r.g0 = (int)f0; r.g1 = (int)f1; r.g2 = (int)f2;
+    r.w0 = p0 - f0; r.w1 = p1 - f1; r.w2 = p2 - f2;
+    const int q0 = __shfl_up(r.g0, 2), q1 = __shfl_up(r.g1, 2), q2 = __shfl_up(r.g2, 2);
+    r.lead = lane < 2 || r.g0 != q0 || r.g1 != q1 || r.g2 != q2;
+    const unsigned long long m = __ballot(r.lead);            // both halves of a sample agree: bits come in pairs
+    r.all = m == ~0ull;
+    const unsigned long long even = m & 0x5555555555555555ull & ((2ull << lane) - 1ull);   // leaders' even lanes <= lane
+    r.src = (63 - __clzll((long long)even)) | (lane & 1);
+    return r;
+}
+
+template <bool HASHED>
+__device__ __forceinline__ void load8(const LevelInfo& li, const char* __restrict__ table, const Lead& c, int half, float4 (&R)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t off = tile::row_offset<HASHED>(li, (uint32_t)c.g0 + (k & 1), (uint32_t)c.g1 + ((k >> 1) & 1),
+                                                       (uint32_t)c.g2 + (k >> 2)) + (uint32_t)half * 16u;
+        R[k] = *reinterpret_cast<const float4*>(table + off);
+    }
+}
+
+// the eight corner pieces of the lane's cell: loaded by run leaders, handed to the rest of the run
+__device__ __forceinline__ void corners(const LevelInfo& li, const float* __restrict__ table, const Lead& c, int half,
+                                        float4 (&R)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) R[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (c.lead) {
+        if (li.flags & 1u) load8<true>(li, reinterpret_cast<const char*>(table), c, half, R);
+        else load8<false>(li, reinterpret_cast<const char*>(table), c, half, R);
+    }
+    if (!c.all) {                                            // wave-uniform
+        const int a = c.src << 2;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            R[k].x = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(R[k].x)));
+            R[k].y = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(R[k].y)));
+            R[k].z = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(R[k].z)));
+            R[k].w = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(R[k].w)));
+        }
+    }
+}
+}  // namespace run
+
+__global__ void __launch_bounds__(256) grid_fwd_run_kernel(GridMeta meta, const float* __restrict__ table,
+                                                           const float* __restrict__ x, int64_t n,
+                                                           float* __restrict__ y, int64_t ldy)
+{
+    using namespace run;
+    __shared__ __attribute__((aligned(16))) float ost[4][S * 32];   // per wave: the tile's (32, 32) outputs, transposed out
+    const uint32_t L = meta.n_levels;
+    const uint32_t wpc = (L + LV - 1) / LV;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wv;
+    // sample-major: the four waves of a workgroup are the four level groups of one tile.  (Level-group-major order — all
+    // tiles for levels 0-3, then 4-7, ... so that a level's rows are re-touched within microseconds — was measured and is
+    // no faster: the gathers are bound by the number of 64-byte L1 misses in flight per CU, not by where they are served.)
+    const int64_t chunk = wave_global / wpc;
+    const uint32_t lg = (uint32_t)(wave_global - chunk * wpc);
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = chunk * S;
+    if (s0 >= n) return;
+    const int j = lane >> 1, half = lane & 1;
+    const int64_t sj = s0 + j < n ? s0 + j : n - 1;
+    const float px = x[3 * sj], py = x[3 * sj + 1], pz = x[3 * sj + 2];
+    float* st = ost[wv];
+#pragma unroll
+    for (int i = 0; i < LV; i++) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (lg * LV + i < L) {                                // wave-uniform
+            const LevelInfo li = level_info(meta, lg * LV + i);
+            const Lead c = phase1(li.scale, px, py, pz, lane);
+            float4 R[8];
+            corners(li, table, c, half, R);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float wt = ((k & 1) ? c.w0 : 1 - c.w0) * ((k & 2) ? c.w1 : 1 - c.w1) * ((k & 4) ? c.w2 : 1 - c.w2);
+                vec_fma<4>(acc, wt, R[k]);
+            }
+        }
+        *reinterpret_cast<float4*>(st + j * 32 + i * 8 + half * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    tile::wave_sync();
+    const int piece = lane & 7;
+    if ((lg * LV + (piece >> 1)) < L) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int js = it * 8 + (lane >> 3);
+            if (s0 + js < n)
+                *reinterpret_cast<float4*>(y + (s0 + js) * ldy + lg * (LV * F) + piece * 4) =
+                    *reinterpret_cast<const float4*>(st + js * 32 + piece * 4);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) grid_bwd_input_run_kernel(GridMeta meta, const float* __restrict__ table,
+                                                                 const float* __restrict__ x,
+                                                                 const float* __restrict__ dL_dy, int64_t lddy,
+                                                                 int64_t n, float* __restrict__ dL_dx)
+{
+    using namespace run;
+    __shared__ __attribute__((aligned(16))) float gst[4][S * 32];   // per wave: the tile's (32, 32) upstream gradients
+    __shared__ float red[4][S * 3];
+    const uint32_t L = meta.n_levels;
+    const uint32_t wpc = (L + LV - 1) / LV;                   // 1, 2 or 4 (checked by the launcher)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t chunk = wave_global / wpc;
+    const uint32_t lg = (uint32_t)(wave_global - chunk * wpc);
+    const int lane = threadIdx.x & 63;
+    const int64_t s0 = chunk * S;
+    const bool active = s0 < n;                               // wave-uniform; the block meets at a barrier below
+    const int j = lane >> 1, half = lane & 1;
+    if (active) {
+        float* st = gst[wv];
+        const int64_t sj = s0 + j < n ? s0 + j : n - 1;
+        const float px = x[3 * sj], py = x[3 * sj + 1], pz = x[3 * sj + 2];
+        {
+            const int piece = lane & 7;
+            const bool have = (lg * LV + (piece >> 1)) < L;
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int js = it * 8 + (lane >> 3);
+                const int64_t sg = s0 + js < n ? s0 + js : n - 1;
+                const float4 v = have ? *reinterpret_cast<const float4*>(dL_dy + sg * lddy + lg * (LV * F) + piece * 4)
+                                      : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                *reinterpret_cast<float4*>(st + js * 32 + piece * 4) = v;
+            }
+            tile::wave_sync();
+        }
+        float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+#pragma unroll
+        for (int i = 0; i < LV; i++) {
+            if (lg * LV + i < L) {
+                const LevelInfo li = level_info(meta, lg * LV + i);
+                const Lead c = phase1(li.scale, px, py, pz, lane);
+                float4 v[8];
+                corners(li, table, c, half, v);
+                const float4 go = *reinterpret_cast<const float4*>(st + j * 32 + i * 8 + half * 4);
+                const float g4[4] = {go.x, go.y, go.z, go.w};
+                const float wx0 = 1 - c.w0, wx1 = c.w0, wy0 = 1 - c.w1, wy1 = c.w1, wz0 = 1 - c.w2, wz1 = c.w2;
+                const float dx = wy0 * wz0 * vec_dot<4>(g4, v[1], v[0]) + wy1 * wz0 * vec_dot<4>(g4, v[3], v[2]) +
+                                 wy0 * wz1 * vec_dot<4>(g4, v[5], v[4]) + wy1 * wz1 * vec_dot<4>(g4, v[7], v[6]);
+                const float dy = wx0 * wz0 * vec_dot<4>(g4, v[2], v[0]) + wx1 * wz0 * vec_dot<4>(g4, v[3], v[1]) +
+                                 wx0 * wz1 * vec_dot<4>(g4, v[6], v[4]) + wx1 * wz1 * vec_dot<4>(g4, v[7], v[5]);
+                const float dz = wx0 * wy0 * vec_dot<4>(g4, v[4], v[0]) + wx1 * wy0 * vec_dot<4>(g4, v[5], v[1]) +
+                                 wx0 * wy1 * vec_dot<4>(g4, v[6], v[2]) + wx1 * wy1 * vec_dot<4>(g4, v[7], v[3]);
+                gx = fmaf(dx, li.scale, gx); gy = fmaf(dy, li.scale, gy); gz = fmaf(dz, li.scale, gz);
+            }
+        }
+        gx += __shfl_xor(gx, 1); gy += __shfl_xor(gy, 1); gz += __shfl_xor(gz, 1);
+        if (!half) { red[wv][3 * j] = gx; red[wv][3 * j + 1] = gy; red[wv][3 * j + 2] = gz; }
+    }
+    __syncthreads();
+    // thread t: tile t / 96 of the block, float t % 96 of its (32, 3) block of dL_dx
+    const int tiles = 4 / (int)wpc;
+    for (int t = threadIdx.x; t < tiles * S * 3; t += 256) {
+        const int tl = t / (S * 3), r = t - tl * (S * 3);
+        const int64_t c0 = ((int64_t)blockIdx.x * 4 + tl * (int)wpc) / wpc * S;
+        if (c0 < n && c0 + r / 3 < n) {
+            float sum = 0.0f;
+            for (uint32_t w = 0; w < wpc; w++) sum += red[tl * wpc + w][r];
+            dL_dx[3 * c0 + r] = sum;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ param gradient (H2)
 // The three kernels below are superseded by grid_bwd_param_slide_kernel and are compiled only into the A/B build
 // (NGP_AB_VARIANTS=1 python -m instant-ngp-pp_amd.build; tools/grid_microbench.py times them against the product kernel).
@@ -817,7 +1300,9 @@ __global__ void __launch_bounds__(256) grid_bwd_param_tag_kernel(GridMeta meta, 
                 const float keepA = mAA ? A[slot] : (mBA ? B[slot] : 0.0f);
                 const float keepB = mBB ? B[slot] : (mAB ? A[slot] : 0.0f);
                 A[slot] = fmaf(wA[slot], gv, keepA);
-                B[slot] = fmaf(wB[slot], gv, keepB);
+                // a B sum without a line (both x-corners in line A: tag INVALID, weight 0) must stay exactly 0 — with a
+                // non-finite gradient 0 * gv is NaN, NaN != 0 would flush it, and INVALID << 4 is not an address of the table
+                B[slot] = nB[slot] == INVALID ? 0.0f : fmaf(wB[slot], gv, keepB);
                 tA[slot] = nA[slot];
                 tB[slot] = nB[slot];
             }
@@ -1134,6 +1619,32 @@ int64_t ngp_grid_layout(int n_levels, int n_features, int log2_hashmap_size, int
         default: return NGP_EINVAL;          \
     }
 
+// A/B build: NGP_GRID_GATHER_OLD=1 (looked up per call, so that one process can time both) selects the
+// item-per-(sample, level) gathers; the product build always takes the tiles for F = 8.
+// the tile kernels take F = 8 layouts whose hashed levels have power-of-two sizes (tcnn's always do) and address
+// the table with 32-bit byte offsets
+static bool tile_layout_ok(const GridMeta& m, const ngp_grid_desc* d)
+{
+    if (m.n_features != 8) return false;
+    if ((uint64_t)d->offsets[m.n_levels] * 32u >= (1ull << 32)) return false;
+    for (uint32_t l = 0; l < m.n_levels; l++) {
+        if ((m.flags[l] & 1u) && !(m.flags[l] & 2u)) return false;
+        if (!(m.flags[l] & 1u) && (uint64_t)m.res[l] * m.res[l] * m.res[l] > m.size[l]) return false;
+    }
+    return true;
+}
+
+static inline int gather_variant()   // 0: item-per-(sample, level), 1: run leaders (product), 2: staged unique cells
+{
+#ifdef NGP_AB_VARIANTS
+    const char* e = getenv("NGP_GRID_GATHER_OLD");
+    return e ? (e[0] == '1' ? 0 : e[0] == '2' ? 2 : 1) : 1;
+#else
+    return 1;
+#endif
+}
+static inline bool tile_gathers() { return gather_variant() != 0; }
+
 static bool ld_ok(const GridMeta& m, int64_t ld, const void* p)
 {
     const int64_t w = (int64_t)m.n_levels * m.n_features;
@@ -1165,8 +1676,17 @@ int ngp_grid_fwd(const ngp_grid_desc* desc, const float* table, const float* x, 
             return ngp_check_launch();
         }
 #endif
-        hipLaunchKernelGGL(grid_fwd_kernel<F>, dim3(ngp_blocks(n_items * LPI, 256)), dim3(256), 0, st, m, table, x,
-                           n_items, y, ldy);
+        if (F == 8 && tile_layout_ok(m, desc) && tile_gathers()) {   // the reference's tables: ray-coherent tiles, one load per unique cell corner
+            const int64_t waves = ((n + tile::S - 1) / tile::S) * ((m.n_levels + tile::LV - 1) / tile::LV);
+            if (gather_variant() == 2)
+                hipLaunchKernelGGL(grid_fwd_tile_kernel, dim3(ngp_blocks(waves * 64, 256)), dim3(256), 0, st, m, table, x, n,
+                                   y, ldy);
+            else
+                hipLaunchKernelGGL(grid_fwd_run_kernel, dim3(ngp_blocks(waves * 64, 256)), dim3(256), 0, st, m, table, x, n,
+                                   y, ldy);
+        } else
+            hipLaunchKernelGGL(grid_fwd_kernel<F>, dim3(ngp_blocks(n_items * LPI, 256)), dim3(256), 0, st, m, table, x,
+                               n_items, y, ldy);
     });
     return ngp_check_launch();
 }
@@ -1280,6 +1800,17 @@ int ngp_grid_bwd_input(const ngp_grid_desc* desc, const float* table, const floa
     if (n == 0) return NGP_OK;
     if (!table || !x || !dL_dy || !dL_dx) return NGP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    const uint32_t wpc = (m.n_levels + tile::LV - 1) / tile::LV;
+    if (4 % wpc == 0 && tile_layout_ok(m, desc) && tile_gathers()) {
+        const int64_t waves = ((n + tile::S - 1) / tile::S) * wpc;
+        if (gather_variant() == 2)
+            hipLaunchKernelGGL(grid_bwd_input_tile_kernel, dim3(ngp_blocks(waves, 4)), dim3(256), 0, st, m, table, x, dL_dy,
+                               lddy, n, dL_dx);
+        else
+            hipLaunchKernelGGL(grid_bwd_input_run_kernel, dim3(ngp_blocks(waves, 4)), dim3(256), 0, st, m, table, x, dL_dy,
+                               lddy, n, dL_dx);
+        return ngp_check_launch();
+    }
     GRID_DISPATCH_F(m.n_features, { launch_bwd_input<F>(m, table, x, dL_dy, lddy, n, dL_dx, st); });
     return ngp_check_launch();
 }

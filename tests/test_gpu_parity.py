@@ -446,6 +446,133 @@ def test_grid_bwd_param_f8_edge_shapes(ngp, L, n):
     close(N(out2), ref, 1e-4, 2e-5 * max(np.abs(ref).max(), 1e-6))
 
 
+def _ray_ordered_points(g, n_rays=320):
+    """samples marched along rays as training feeds them (step sqrt(3)/1024): both directions along every axis,
+    diagonals, coarse-step rays, stuck samples; segment lengths that are no multiple of the tile length"""
+    step = np.float32(3 ** 0.5 / 1024)
+    dirs = [g.normal(size=3) for _ in range(n_rays - 10)]
+    dirs += [np.array(v, float) for v in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1),
+                                          (1, 1, 1), (-1, -1, -1), (1, -1, 0), (0, 1, -1))]
+    xs = []
+    for i, d in enumerate(dirs):
+        d = d / np.linalg.norm(d)
+        o = g.random(3) * 0.5 + 0.25
+        cnt = int(g.integers(1, 90))
+        st = step * (5.0 if i % 17 == 0 else 1.0)
+        t = np.arange(cnt, dtype=np.float32) * st
+        pts = o[None, :] + d[None, :] * t[:, None]
+        if i % 11 == 0:
+            pts[cnt // 2:] = pts[cnt // 2]
+        xs.append(pts)
+    return np.clip(np.concatenate(xs), 0.0, 1.0).astype(np.float32)
+
+
+@pytest.mark.parametrize("log2T", [14, 19])
+def test_grid_gathers_ray_ordered(ngp, log2T):
+    """The F = 8 gathers load each UNIQUE cell of a 32-sample tile once (runs of consecutive samples in one cell share
+    the staged corners).  Random points never form runs; this feeds ray-ordered samples, through a plain and a
+    column-window output / gradient matrix (the field's rgb_in[:, 16:])."""
+    from ngp_amd._lib import call
+    L, Fd, base, pls = 16, 8, 16, 1.3195079107728942
+    desc, n_params = oracle.grid_layout(L, Fd, log2T, base, pls)
+    g = rng(160 + log2T)
+    x = _ray_ordered_points(g)
+    n = x.shape[0]
+    table = g.uniform(-1, 1, n_params).astype(np.float32)
+    gd = ngp._lib.GridDesc()
+    assert ngp._lib.call_host("grid_layout", L, Fd, log2T, base, pls, gd) == n_params
+    ref = oracle.grid_fwd(desc, table, x)
+    tt, xt = T(table), T(x)
+    y = torch.full((n, L * Fd), 7.0, device=DEV)
+    call("grid_fwd", gd, tt, xt, n, y, L * Fd)
+    close(N(y), ref, 1e-5, 1e-6)
+    wide = torch.full((n, 16 + L * Fd + 8), 7.0, device=DEV)       # column window: 64-byte offset, 608-byte rows
+    call("grid_fwd", gd, tt, xt, n, wide[:, 16:], wide.shape[1])
+    assert torch.equal(wide[:, 16:16 + L * Fd], y)
+    assert bool((wide[:, :16] == 7.0).all()) and bool((wide[:, 16 + L * Fd:] == 7.0).all())
+    dy = g.normal(size=(n, L * Fd)).astype(np.float32)
+    dy[g.random(n) < 0.2] = 0.0
+    rgx = oracle.grid_bwd_input(desc, table, x, dy)
+    gx = torch.full((n, 3), 7.0, device=DEV)
+    call("grid_bwd_input", gd, tt, xt, T(dy), L * Fd, n, gx)
+    close(N(gx), rgx, 2e-4, 3e-6 * np.abs(rgx).max())
+    dyw = torch.zeros(n, L * Fd + 24, device=DEV)
+    dyw[:, 16:16 + L * Fd] = T(dy)
+    gx2 = torch.zeros(n, 3, device=DEV)
+    call("grid_bwd_input", gd, tt, xt, dyw[:, 16:], dyw.shape[1], n, gx2)
+    assert torch.equal(gx2, gx)
+
+
+@pytest.mark.parametrize("L,n", [(1, 1), (4, 31), (5, 15), (6, 33), (8, 32), (12, 70), (16, 1), (16, 31), (16, 32),
+                                 (16, 33), (16, 65), (10, 1000), (3, 129)])
+def test_grid_gathers_f8_edge_shapes(ngp, L, n):
+    """Tiles of 32 samples x 4 levels per wave: level counts that are no multiple of four (idle level slots, and for
+    the input gradient 3 waves per tile -> the item-per-(sample, level) kernel), batches shorter than a tile, ending
+    one sample before / at / behind a tile boundary, repeated positions, the far corner, a tiny table (collisions)."""
+    from ngp_amd._lib import call
+    Fd, base, pls, log2T = 8, 4, 1.7, 9
+    desc, n_params = oracle.grid_layout(L, Fd, log2T, base, pls)
+    g = rng(950 + 31 * L + n)
+    x = g.random((n, 3)).astype(np.float32)
+    if n > 4:
+        x[n // 2:n // 2 + 3] = x[n // 2]
+        x[-1] = [1.0, 1.0, 1.0]
+        x[0] = [0.0, 0.0, 0.0]
+    table = g.uniform(-1, 1, n_params).astype(np.float32)
+    gd = ngp._lib.GridDesc()
+    assert ngp._lib.call_host("grid_layout", L, Fd, log2T, base, pls, gd) == n_params
+    guard = 64
+    ybuf = torch.full((n * L * Fd + 2 * guard,), 7.0, device=DEV)
+    y = ybuf[guard:guard + n * L * Fd].view(n, L * Fd)
+    call("grid_fwd", gd, T(table), T(x), n, y, L * Fd)
+    close(N(y), oracle.grid_fwd(desc, table, x), 1e-5, 1e-6)
+    assert bool((ybuf[:guard] == 7.0).all()) and bool((ybuf[-guard:] == 7.0).all())
+    dy = g.normal(size=(n, L * Fd)).astype(np.float32)
+    rgx = oracle.grid_bwd_input(desc, table, x, dy)
+    gbuf = torch.full((n * 3 + 2 * guard,), 7.0, device=DEV)
+    gx = gbuf[guard:guard + n * 3].view(n, 3)
+    call("grid_bwd_input", gd, T(table), T(x), T(dy), L * Fd, n, gx)
+    close(N(gx), rgx, 2e-4, 3e-6 * max(np.abs(rgx).max(), 1e-6))
+    assert bool((gbuf[:guard] == 7.0).all()) and bool((gbuf[-guard:] == 7.0).all())
+
+
+def test_grid_bwd_param_nonfinite_gradient_stays_in_table(ngp):
+    """A non-finite upstream gradient must reach only the rows its sample touches: the F = 8 scatter keeps a second
+    running sum per corner slot whose line tag is INVALID when both x-corners share a 64-byte line; 0 * inf = NaN in
+    that sum must not be flushed (the INVALID tag is not an address of the table)."""
+    from ngp_amd._lib import call
+    L, Fd, base, pls, log2T = 16, 8, 16, 1.3195079107728942, 14
+    desc, n_params = oracle.grid_layout(L, Fd, log2T, base, pls)
+    g = rng(970)
+    x = _ray_ordered_points(g, n_rays=40)
+    n = x.shape[0]
+    dy = g.normal(size=(n, L * Fd)).astype(np.float32)
+    bad_inf, bad_nan = n // 3, 2 * n // 3
+    x[bad_inf] = [0.3137, 0.4242, 0.5151]                    # strictly inside cells: no exactly-zero corner weights
+    x[bad_nan] = [0.6161, 0.2727, 0.7373]
+    dy[bad_inf] = np.inf
+    dy[bad_nan] = np.nan
+    gd = ngp._lib.GridDesc()
+    assert ngp._lib.call_host("grid_layout", L, Fd, log2T, base, pls, gd) == n_params
+    guard = 1 << 16
+    buf = torch.zeros(n_params + 2 * guard, device=DEV)
+    out = buf[guard:guard + n_params]
+    call("grid_bwd_param", gd, T(x), T(dy), L * Fd, n, out)
+    torch.cuda.synchronize()
+    assert bool((buf[:guard] == 0).all()) and bool((buf[-guard:] == 0).all())
+    # rows touched by finite samples only are finite and equal the oracle's on the finite part of the batch
+    fin = np.ones(n, bool)
+    fin[[bad_inf, bad_nan]] = False
+    touched_bad = oracle.grid_bwd_param(desc, x[~fin], np.ones((2, L * Fd), np.float32), n_params) != 0
+    # the kernel accumulates per 64-byte line (two rows): 0 * NaN also reaches the other row of a touched line
+    touched_bad = np.repeat(touched_bad.reshape(-1, 2 * Fd).any(1), 2 * Fd)
+    ref = oracle.grid_bwd_param(desc, x[fin], dy[fin], n_params)
+    got = N(out)
+    assert np.isfinite(got[~touched_bad]).all()
+    close(got[~touched_bad], ref[~touched_bad], 1e-4, 2e-5 * np.abs(ref).max())
+    assert not np.isfinite(got[touched_bad]).all()          # the bad samples did poison their own rows
+
+
 def test_grid_double_backward(ngp):
     L, Fd, log2T, base, pls, n = 8, 8, 15, 16, 1.5, 600
     tcnn = ngp.tinycudann

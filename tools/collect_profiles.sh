@@ -7,9 +7,9 @@
 #   ${R}_timeline_grid_update_step.txt   a step that starts with a density-grid update
 #   ${R}_pmc_traffic.json           FETCH_SIZE / WRITE_SIZE / TCC_EA0_ATOMIC of the grid kernels and Adam (separate --pmc passes)
 # Traces go to /tmp (they exceed the 64 MiB that travels back); only summaries are copied.
-# usage: bash tools/collect_profiles.sh [nopmc]      (R=r02 by default; R=r03 bash tools/... for the next round)
+# usage: bash tools/collect_profiles.sh [nopmc]      (R=r03 by default)
 set -e -o pipefail
-R=${R:-r02}
+R=${R:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/prof
 python3 bench.py > gpurun_out/prof/bench.log 2>&1

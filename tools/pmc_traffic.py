@@ -26,7 +26,7 @@ def last(dirpath, counter, like, n):
 def main():
     fdir, wdir, steps, samples = sys.argv[1], sys.argv[2], int(sys.argv[3]), float(sys.argv[4])
     out = {}
-    for name, like, per_step in (("grid_bwd_param", "grid_bwd_param", 2), ("grid_fwd", "grid_fwd_kernel", 2),
+    for name, like, per_step in (("grid_bwd_param", "grid_bwd_param", 2), ("grid_fwd", "grid_fwd", 2),
                                  ("grid_bwd_input", "grid_bwd_input", 1)):
         f = last(fdir, "FETCH_SIZE", like, steps * per_step) * 1024
         w = last(wdir, "WRITE_SIZE", like, steps * per_step) * 1024
