@@ -75,9 +75,23 @@ def build(force=False, verbose=False):
     want = source_id()
     if not force and os.path.exists(LIB) and built_id() == want:
         return LIB
-    hipcc = _hipcc()
+    # several ranks of one launch may find a stale library at once: one of them builds, the others wait on the lock
+    # and find the work done; objects and the library are written under temporary names and renamed into place
+    import fcntl
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and os.path.exists(LIB) and built_id() == want:
+                return LIB
+            return _build_locked(want, objdir, force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(want, objdir, force, verbose):
+    hipcc = _hipcc()
     objs = []
     units = [(s, fl, []) for s, fl in SOURCES] + [("build_id.cpp", [], [f'-DNGP_BUILD_ID="{want}"'])]
     for src, extra, defs in units:
@@ -87,19 +101,26 @@ def build(force=False, verbose=False):
         stamp = o + ".sha"
         have = open(stamp).read().strip() if os.path.exists(stamp) and os.path.exists(o) else None
         if force or have != d:
-            cmd = [hipcc] + _flags() + extra + defs + ["-c", s, "-o", o]
+            tmp_o = o + f".{os.getpid()}.tmp"
+            cmd = [hipcc] + _flags() + extra + defs + ["-c", s, "-o", tmp_o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+            os.replace(tmp_o, o)
             with open(stamp, "w") as f:
                 f.write(d)
         objs.append(o)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    tmp_lib = LIB + f".{os.getpid()}.tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    with open(LIB_ID, "w") as f:
+    if os.path.exists(LIB_ID):
+        os.remove(LIB_ID)           # never a new library beside an old id, or the reverse
+    os.replace(tmp_lib, LIB)
+    with open(LIB_ID + ".tmp", "w") as f:
         f.write(want)
+    os.replace(LIB_ID + ".tmp", LIB_ID)
     return LIB
 
 

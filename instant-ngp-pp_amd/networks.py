@@ -377,7 +377,8 @@ class _FieldFn(Function):
             n_rays = rays_a.shape[0]
             offsets = torch.empty(n_rays, dtype=torch.int32, device=dev)
             bufs["live_idx"] = torch.empty(n, dtype=torch.int32, device=dev)
-            bufs["inv_idx"] = torch.empty(n, dtype=torch.int32, device=dev)
+            # -1 = "not in the list": ngp_live_rows writes only the rows its rays_a segments cover, the spread kernels read all n
+            bufs["inv_idx"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
             n_live_dev = torch.empty(1, dtype=torch.int32, device=dev)
             bufs["xn_c"] = torch.empty(n, 3, dtype=_f32, device=dev)   # the first n_live rows are used
             bufs["d_c"] = torch.empty(n, 3, dtype=_f32, device=dev)

@@ -249,3 +249,62 @@ def test_empty_and_negative_batches_through_the_c_abi(ngp):
             assert getattr(lib, name)(*build(0)) == 0, name
         checked += 1
     assert checked >= 40
+
+
+# ---------------------------------------------------------------------------- inline-assembly loads of the product build
+_ASM_BAD = """
+_Z10fake_kernelv:
+.LBB0_1:                                ; =>This Inner Loop Header: Depth=1
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[10:13], v[2:3], off offset:0
+\t;;#ASMEND
+\tglobal_store_dword v[4:5], v6, off
+{between}
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(1)
+\t;;#ASMEND
+\tv_add_f32_e32 v20, v10, v11
+\ts_cbranch_scc1 .LBB0_1
+\ts_endpgm
+"""
+
+
+def _run_checker(path, want):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_loads.py"), path, want],
+                          capture_output=True, text=True)
+
+
+def test_asm_load_checker_detects_violations(tmp_path):
+    """the checker itself: a use, a copy or an overwrite of a load destination before the covering wait is a finding;
+    the same stream without it is clean; a wait that does not cover the load (vmcnt too large) is a finding"""
+    cases = {"clean": ("\tv_mul_f32_e32 v30, v31, v32", 0), "read": ("\tv_mov_b32_e32 v40, v11", 1),
+             "overwrite": ("\tv_mov_b32_e32 v12, 0", 1), "spill": ("\tscratch_store_dwordx4 off, v[10:13], off", 1)}
+    for name, (between, rc) in cases.items():
+        p = tmp_path / f"{name}.s"
+        p.write_text(_ASM_BAD.format(between=between))
+        r = _run_checker(str(p), "fake_kernel")
+        assert r.returncode == rc, (name, r.stdout)
+    p = tmp_path / "uncovered.s"
+    p.write_text(_ASM_BAD.format(between="").replace("vmcnt(1)", "vmcnt(2)"))
+    assert _run_checker(str(p), "fake_kernel").returncode == 1
+
+
+def test_product_build_asm_loads_are_covered(ngp, tmp_path):
+    """mlp_stream_fwd_kernel / mlp_stream_dgrad_kernel prefetch their rows with inline-assembly loads and hand-placed
+    s_waitcnt vmcnt(N): compile the PRODUCT source with the PRODUCT flags to ISA and check that no instruction touches a
+    load destination before the wait that covers it (a compiler update that re-schedules around the asm statements must
+    fail here, on the CPU, not fault on the GPU)."""
+    from ngp_amd import build
+    if not build.have_hipcc():
+        pytest.skip("hipcc not available")
+    flags = [f for f in build.COMMON if f != "-fPIC"]
+    out = tmp_path / "mlp_kernels.s"
+    subprocess.check_call([build._hipcc()] + flags + ["-S", "--cuda-device-only", "-o", str(out),
+                                                      os.path.join(build.CSRC, "mlp_kernels.hip")],
+                          stderr=subprocess.DEVNULL)
+    r = _run_checker(str(out), "mlp_stream_")
+    assert r.returncode == 0, r.stdout[-4000:]
+    lines = [l for l in r.stdout.splitlines() if "loop of" in l]
+    with_loads = [l for l in lines if " 0 asm loads" not in l]
+    assert any("mlp_stream_fwd_kernel" in l for l in with_loads) and any("mlp_stream_dgrad_kernel" in l for l in with_loads), \
+        "the checker found no inline-assembly loads in the streaming kernels: its parsing no longer matches the ISA listing"
