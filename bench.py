@@ -370,12 +370,23 @@ def main():
     per_step = {}
     for ev in comm_trace:
         key = (ev["op"], ev["bucket"], ev["stream"])
-        per_step[key] = per_step.get(key, 0) + ev["bytes"] / post_steps
+        acc = per_step.setdefault(key, [0.0, 0.0, 0])
+        acc[0] += ev["bytes"] / post_steps
+        if "events" in ev:
+            acc[1] += ev["events"][0].elapsed_time(ev["events"][1])
+            acc[2] += 1
     comm = {"backend": (dist.get_backend() if dist.is_initialized() else None), "world_size": world,
             "sharded_optimizer": bool(trainer.sharded),
-            "per_step": [{"op": op, "bucket": b, "MB": round(v / 1e6, 3),
+            "per_step": [{"op": op, "bucket": b, "MB": round(v[0] / 1e6, 3),
+                          "ms": (round(v[1] / v[2], 4) if v[2] else None),
+                          # payload / time, and the bus bandwidth of a ring / direct reduce-scatter or all-gather of that payload
+                          "GBps": (round(v[0] * post_steps / v[2] / (v[1] / v[2] * 1e-3) / 1e9, 2) if v[2] and v[1] > 0 else None),
+                          "bus_GBps": (round((world - 1) / max(world, 1) * v[0] * post_steps / v[2] / (v[1] / v[2] * 1e-3) / 1e9, 2)
+                                       if v[2] and v[1] > 0 else None),
                           "enqueued_behind": "main stream" if st == main_stream else f"side stream {st:#x}"}
-                         for (op, b, st), v in sorted(per_step.items())]}
+                         for (op, b, st), v in sorted(per_step.items())],
+            "note": "ms: HIP events on the issuing stream around each collective in the traced steps behind the timed region, "
+                    "where every collective is waited for at once (its own duration, not the overlapped schedule)"}
     if world > 1 or solo_group:
         try:
             rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else "n/a"
@@ -383,7 +394,8 @@ def main():
             rccl = "unknown"
         print(f"[rank {rank}] {comm['backend']} world size {dist.get_world_size()} (RCCL {rccl}), "
               f"sharded optimizer {trainer.sharded}; per step: " +
-              "; ".join(f"{c['op']} bucket {c['bucket']} {c['MB']} MB behind {c['enqueued_behind']}" for c in comm["per_step"]),
+              "; ".join(f"{c['op']} bucket {c['bucket']} {c['MB']} MB {c['ms']} ms ({c['bus_GBps']} GB/s bus) behind {c['enqueued_behind']}"
+                        for c in comm["per_step"]),
               file=sys.stderr, flush=True)
     prof.update(prof_live)
     # the field calls the scaled entry point, other callers the plain one: one kernel, one entry in the tables

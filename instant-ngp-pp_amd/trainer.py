@@ -55,10 +55,27 @@ class GradBuckets:
         # call was enqueued behind) — bench.py --gpus N prints it per rank
         self.trace = None
 
-    def _note(self, op, i, nbytes):
-        if self.trace is not None:
-            st = torch.cuda.current_stream().cuda_stream if self.flat.is_cuda else 0
-            self.trace.append({"op": op, "bucket": int(i), "bytes": int(nbytes), "stream": int(st)})
+    def _issue(self, op, i, nbytes, fn):
+        """runs fn() (which issues one collective and returns its work object or None).  With `trace` set the
+        collective is also TIMED: HIP events on the issuing stream before the call and behind the work's completion
+        (the work is waited for at once, so the traced steps serialise their collectives: durations are those of
+        each collective by itself beside whatever the other streams run, not the overlapped schedule)."""
+        if self.trace is None:
+            return fn()
+        rec = {"op": op, "bucket": int(i), "bytes": int(nbytes),
+               "stream": int(torch.cuda.current_stream().cuda_stream) if self.flat.is_cuda else 0}
+        if self.flat.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            w = fn()
+            if w is not None:
+                w.wait()
+            e1.record()
+            rec["events"] = (e0, e1)
+        else:
+            w = fn()
+        self.trace.append(rec)
+        return w
 
     @property
     def world(self):
@@ -80,36 +97,38 @@ class GradBuckets:
         if self.world == 1 and self.solo:
             return
         lo, hi = self.bounds[i], self.bounds[i + 1]
-        self._note("all_reduce", i, 4 * (hi - lo))
-        self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.works.append(self._issue("all_reduce", i, 4 * (hi - lo), lambda: dist.all_reduce(
+            self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def reduce_scatter_bucket(self, i, out):
         """out (own buffer, 1/world of the bucket) <- this rank's slice of the bucket summed over ranks"""
         if self.world == 1 and self.solo:
             return
         lo, hi = self.bounds[i], self.bounds[i + 1]
-        self._note("reduce_scatter", i, 4 * (hi - lo))
         if self._native_rs():
-            self.works.append(dist.reduce_scatter_tensor(out, self.flat[lo:hi], op=dist.ReduceOp.SUM,
-                                                         group=self.group, async_op=True))
+            self.works.append(self._issue("reduce_scatter", i, 4 * (hi - lo), lambda: dist.reduce_scatter_tensor(
+                out, self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
         else:  # gloo has no reduce-scatter: all-reduce, then the owner copies its slice out
             a, b = self.shard_range(i)
-            w = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            w.wait()
-            out.copy_(self.flat[a:b])
+
+            def via_all_reduce():
+                dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+                out.copy_(self.flat[a:b])
+            self._issue("reduce_scatter", i, 4 * (hi - lo), via_all_reduce)
+            self.works.append(None)       # one entry per bucket, in issue order (NGPTrainer sums each shard behind its own)
 
     def all_gather_bucket(self, i, flat_param, shard, detach=False):
         """flat_param[bucket i] <- concatenation over ranks of `shard` (own buffer)"""
         if self.world == 1 and self.solo:
             return None
         lo, hi = self.bounds[i], self.bounds[i + 1]
-        self._note("all_gather", i, 4 * (hi - lo))
         if self._native_rs():
-            w = dist.all_gather_into_tensor(flat_param[lo:hi], shard, group=self.group, async_op=True)
+            w = self._issue("all_gather", i, 4 * (hi - lo), lambda: dist.all_gather_into_tensor(
+                flat_param[lo:hi], shard, group=self.group, async_op=True))
         else:
             s = (hi - lo) // self.world
             views = [flat_param[lo + r * s: lo + (r + 1) * s] for r in range(self.world)]
-            w = dist.all_gather(views, shard, group=self.group, async_op=True)
+            w = self._issue("all_gather", i, 4 * (hi - lo), lambda: dist.all_gather(views, shard, group=self.group, async_op=True))
         if detach:
             return w   # the caller waits for it where the gathered parameters are first read
         self.works.append(w)
@@ -117,8 +136,14 @@ class GradBuckets:
 
     def wait(self):
         for w in self.works:
-            w.wait()
+            if w is not None:
+                w.wait()
         self.works = []
+
+    def take_works(self):
+        """hands the pending work objects (issue order) to the caller, who waits for them one by one"""
+        ws, self.works = self.works, []
+        return ws
 
 
 def shard_seed(base_seed, rank):
@@ -396,11 +421,24 @@ class NGPTrainer:
         self.scalars.zero_()
         # sharded: bucket 0's reduce-scatter was issued from the colour encoder's backward
         nb = len(self.buckets.bounds) - 1
-        for i in range(1 if self.hooked0 else 0, nb):
+        first = 1 if self.hooked0 else 0
+        for i in range(first, nb):
             self.buckets.reduce_scatter_bucket(i, self.grad_shard[i])
-        self.buckets.wait()
-        # all contributions are in the shard buffers now: clear the 0.8 GB accumulation buffer on the
-        # optimizer stream, beside the norm / Adam of the slices; the next step joins before it starts
+        # global gradient norm = sqrt(sum over ranks of the shard sums).  Every shard is summed as soon as ITS
+        # reduce-scatter has landed: the colour table's share (77 % of the entries) is read while the second bucket
+        # is still on the wire (the one-GPU path's early norm share, kept in the sharded path).
+        works = self.buckets.take_works()
+        order = ([0] if self.hooked0 else []) + list(range(first, nb))
+        assert len(works) == len(order)
+        for w, i in zip(works, order):
+            if w is not None:
+                w.wait()
+            g = self.grad_shard[i]
+            call("sumsq", g, g.numel(), self.scalars[0:1])
+        # all contributions are in the shard buffers now.  The scatter kernels add into flat_grad, so it has to be zero
+        # again before the next backward: Adam clears only the rank's own 1/N (the shard buffers), the other (N-1)/N of
+        # the accumulation buffer has no kernel that reads it on this rank — one 0.8 GB fill (0.15 ms of HBM writes) on
+        # the optimizer stream, beside the norm / Adam of the slices and the all-gathers; the next backward joins it
         if self._opt_stream is not None:
             self._opt_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._opt_stream):
@@ -409,8 +447,6 @@ class NGPTrainer:
                 self._grad_zeroed.record(self._opt_stream)
         else:
             self.flat_grad.zero_()
-        for g in self.grad_shard:           # global grad norm = sqrt(sum over ranks of shard sums)
-            call("sumsq", g, g.numel(), self.scalars[0:1])
         dist.all_reduce(self.scalars[0:1], op=dist.ReduceOp.SUM, group=self.group)
         call("clip_coef", self.scalars[0:1], float(self.clip_norm), 1.0 / world, self.scalars[1:2])
         # per bucket: Adam on the slice, then publish it.  [density table | MLPs] first, the colour table
