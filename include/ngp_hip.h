@@ -244,6 +244,23 @@ int ngp_distortion_loss_bw(const float* dL_dloss, const float* ws_inclusive_scan
 int ngp_nerf_loss(const float* rgb, const float* target_rgb, const float* opacity,
                   const float* distortion, int n_rays, float lambda_opacity, float lambda_distortion,
                   float* terms /* (4), caller zeroes */, float* d_rgb, float* d_opacity, void* stream);
+/* Default training recipe, everything between the field's raw outputs and the field's backward in ONE launch
+ * (replaces, with the same arithmetic per ray: -F.normalize of d sigma/dx (scaled by scale3, device (3) or NULL) and of
+ * the normal head, networks.py:198,215; softmax of the class logits, networks.py:219; composite_train_fw,
+ * volumerendering.cu:65-164; the RefLoss inputs and forward, rendering.py:243-249 + ref_loss.cu; distortion_loss_fw/bw,
+ * losses.cu; NeRFLoss's rgb / opacity / distortion terms reduced as sum(term.mean()), losses.py:96-105, train.py:307;
+ * composite_train_bw, volumerendering.cu:167-311).  Outputs: the per-ray results of render() (total_samples int64,
+ * opacity, depth, rgb, normal_pred, semantic, Ro = loss_o, Rp = loss_p (n_rays,3)), ws (N), vr_samples (1) int64 =
+ * sum of total_samples, terms (4) = [loss, rgb, opacity, distortion], and the loss's gradients w.r.t. the field's
+ * outputs dL_dsigmas (N), dL_drgbs (N,3).  terms and vr_samples are cleared here.  rays_a must cover every sample row;
+ * classes <= 8; normal_head / sem_logits rows may be strided (ld_*). */
+int ngp_render_loss_fused(const float* sigmas, const float* rgbs, const float* dsigma_dx, const float* scale3,
+                          const float* normal_head, int64_t ld_normal, const float* sem_logits, int64_t ld_sem,
+                          const float* dirs, const float* deltas, const float* ts, const int64_t* rays_a,
+                          const float* target_rgb, float T_threshold, int classes, int n_rays, float lambda_opacity,
+                          float lambda_distortion, int64_t* total_samples, int64_t* vr_samples, float* opacity,
+                          float* depth, float* rgb, float* normal_pred, float* sem, float* ws, float* loss_o,
+                          float* loss_p, float* terms, float* dL_dsigmas, float* dL_drgbs, void* stream);
 int ngp_refloss_inputs(const float* normals_raw, const float* normals_pred, const float* dirs, int64_t n,
                        float* normals_diff, float* normals_ori, void* stream);
 int ngp_neg_normalize(const float* x, int64_t ldx, const float* scale3 /* device (3) or NULL */, int64_t n,
@@ -381,6 +398,10 @@ int ngp_linear_bwd_weight(const float* dz, int64_t lddz, const float* x, int64_t
 
 int ngp_act_bwd(const float* dy, const float* y, int64_t count, int activation,
                 float* dz, void* stream);
+/* the same over (n, cols <= 4) rows, which also accumulates sum_rows ||dz[row, :]||_2 into *row_norm_acc (what
+ * ngp_row_norm_sum would compute from dz afterwards: the norm-bound sums of ngp_clip_decide without a launch of their own) */
+int ngp_act_bwd_rows(const float* dy, const float* y_or_z, int64_t n, int cols, int activation, float* dz,
+                     float* row_norm_acc, void* stream);
 
 int ngp_mlp_hidden_bwd(const float* dOut, int64_t lddo, const float* out, int64_t ldo, int act2,
                        const float* W2, int64_t ldw2, const float* hidden, int64_t ldh, int act1,
@@ -442,6 +463,12 @@ int ngp_row_norm_sum(const float* x, int64_t ldx, int64_t n, int cols, float* ou
 int ngp_clip_decide(const float* row_norm_sums, const float* w1_a, int64_t n1_a, const float* w2_a, int64_t n2_a,
                     const float* w1_b, int64_t n1_b, const float* w2_b, int64_t n2_b, const float* sumsq_rest,
                     float max_norm, float extra_scale, float* coef, int32_t* need_exact, void* stream);
+/* ngp_clip_decide with the exact part summed by the same launch: *sumsq (in: what has been summed already, usually 0)
+ * += sum of squares of rest[0:n_rest] (the MLP gradients, ~40 k entries), then the decision as above with it. */
+int ngp_clip_decide_rest(const float* row_norm_sums, const float* w1_a, int64_t n1_a, const float* w2_a, int64_t n2_a,
+                         const float* w1_b, int64_t n1_b, const float* w2_b, int64_t n2_b, const float* rest,
+                         int64_t n_rest, float* sumsq, float max_norm, float extra_scale, float* coef,
+                         int32_t* need_exact, void* stream);
 int ngp_sumsq_if(const float* x, int64_t n, float* out, const int32_t* flag, void* stream);
 int ngp_clip_coef_if(const float* sumsq, float max_norm, float extra_scale, float* coef, const int32_t* flag,
                      void* stream);

@@ -492,6 +492,212 @@ __global__ void __launch_bounds__(256) nerf_loss_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------ fused render + default loss + its gradients
+// Everything between the field's raw outputs and the field's backward on the default recipe (rendering.py:221-249,
+// losses.py:96-105, train.py:307), per ray, in ONE launch (it replaces -normalize x2, softmax, composite_train_fw,
+// the RefLoss inputs + forward, distortion fw/bw, the loss and composite_train_bw: 12 launches on a serial chain):
+//   pass A  compositing with early stop: ws, opacity, depth, rgb, normal_pred, semantic, total_samples, Ro, Rp, and the
+//           distortion loss of the ray (running inclusive scans of w and w t);
+//           per-sample normals (-normalize of d sigma/dx and of the head's output) and softmax live in registers only;
+//   seeds   d_rgb = 2 (rgb - gt) / (3 R), d_opacity = lambda_o (-log o - 1) / R, d_dist = lambda_d / R; loss terms;
+//   pass B  tot = sum_s dL_dws[s] ws[s] (distortion backward in closed form, losses.cu:130-139);
+//   pass C  composite_train_bw's scans: dL_dsigmas, dL_drgbs (volumerendering.cu:193-245; normal / semantic terms do not
+//           enter dL_dsigma there, and their own gradients are zero on this recipe).
+// Every lane re-reads only what the SAME lane wrote (ws), the scans are recomputed: no cross-lane traffic through memory.
+struct RenderLossArgs {
+    const float *sigmas, *rgbs, *dsig_dx, *np_raw, *sem_logits, *dirs, *deltas, *ts, *gt, *scale3;
+    const int64_t* rays_a;
+    int64_t ld_np, ld_sem;
+    float T_thr, g_rgb, g_op, g_dist;
+    int classes, n_rays;
+    int64_t *total_samples, *vr_samples;
+    float *opacity, *depth, *rgb, *normal, *sem, *ws, *Ro, *Rp, *terms, *d_sigmas, *d_rgbs;
+};
+
+template <int CMAX>
+__global__ void __launch_bounds__(256) render_loss_fused_kernel(RenderLossArgs p)
+{
+    __shared__ float part[3][8];
+    __shared__ unsigned long long part_n[8];
+    Seg sg; int lane;
+    const bool have = seg_load(p.rays_a, p.n_rays, sg, lane);
+    float s_rgb = 0.0f, s_op = 0.0f, s_dist = 0.0f;
+    unsigned long long n_used = 0;
+    if (have) {
+        const size_t r = (size_t)sg.ray;
+        const float sc0 = p.scale3 ? p.scale3[0] : 1.0f, sc1 = p.scale3 ? p.scale3[1] : 1.0f, sc2 = p.scale3 ? p.scale3[2] : 1.0f;
+        // ---------------- pass A
+        float T_run = 1.0f;
+        float aO = 0, aD = 0, aR = 0, aG = 0, aB = 0, aNx = 0, aNy = 0, aNz = 0, aRo = 0, aPx = 0, aPy = 0, aPz = 0;
+        float aS[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; c++) aS[c] = 0;
+        float w_run = 0, wt_run = 0, dacc = 0;
+        int stop = -1;
+        int k0 = 0;
+        for (; k0 < sg.n; k0 += 32) {
+            const int k = k0 + lane;
+            const int64_t s = sg.start + k;
+            const Chunk c = chunk_alpha(p.sigmas, p.deltas, s, k < sg.n, T_run, p.T_thr, lane);
+            const float w = c.active ? c.a * c.T_before : 0.0f;
+            float tt = 0.0f, dl = 0.0f;
+            if (c.valid) {
+                p.ws[s] = w;
+                tt = p.ts[s]; dl = p.deltas[s];
+            }
+            if (c.active) {   // samples behind the stop carry no weight: their normals / classes are not needed
+                aO += w;
+                aD += w * tt;
+                aR += w * p.rgbs[3 * s]; aG += w * p.rgbs[3 * s + 1]; aB += w * p.rgbs[3 * s + 2];
+                // normals_raw = -normalize(d sigma/dx * scale3), normals_pred = -normalize(head), eps 1e-6 (F.normalize)
+                float gx = p.dsig_dx[3 * s] * sc0, gy = p.dsig_dx[3 * s + 1] * sc1, gz = p.dsig_dx[3 * s + 2] * sc2;
+                float inv = -1.0f / fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-6f);
+                gx *= inv; gy *= inv; gz *= inv;
+                float hx = p.np_raw[s * p.ld_np], hy = p.np_raw[s * p.ld_np + 1], hz = p.np_raw[s * p.ld_np + 2];
+                inv = -1.0f / fmaxf(sqrtf(hx * hx + hy * hy + hz * hz), 1e-6f);
+                hx *= inv; hy *= inv; hz *= inv;
+                aNx += w * hx; aNy += w * hy; aNz += w * hz;
+                // Ref-NeRF regularisers (rendering.py:243-245)
+                const float ex = gx - hx, ey = gy - hy, ez = gz - hz;
+                aPx += w * (ex * ex); aPy += w * (ey * ey); aPz += w * (ez * ez);
+                const float dx = p.dirs[3 * s], dy = p.dirs[3 * s + 1], dz = p.dirs[3 * s + 2];
+                const float dinv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
+                const float dot = fmaxf((gx * dx + gy * dy + gz * dz) * dinv, 0.0f);
+                aRo += w * (dot * dot);
+                // softmax over the class logits
+                float lg[CMAX], mx = -INFINITY;
+#pragma unroll
+                for (int cc = 0; cc < CMAX; cc++) {
+                    lg[cc] = cc < p.classes ? p.sem_logits[s * p.ld_sem + cc] : -INFINITY;
+                    mx = fmaxf(mx, lg[cc]);
+                }
+                float den = 0.0f;
+#pragma unroll
+                for (int cc = 0; cc < CMAX; cc++) { lg[cc] = cc < p.classes ? __expf(lg[cc] - mx) : 0.0f; den += lg[cc]; }
+                const float winv = w / den;
+#pragma unroll
+                for (int cc = 0; cc < CMAX; cc++) aS[cc] += winv * lg[cc];
+            }
+            // distortion loss (losses.cu:8-59): inclusive scans of w and w t over the ray
+            const float wt = w * tt;
+            const float wi = w_run + half_incl_scan_add(w, lane);
+            const float wti = wt_run + half_incl_scan_add(wt, lane);
+            float we = __shfl_up(wi, 1, 32), wte = __shfl_up(wti, 1, 32);
+            if (lane == 0) { we = w_run; wte = wt_run; }
+            if (c.valid) dacc += 2 * (wti * we - wi * wte) + 1.0f / 3 * w * w * dl;
+            w_run = __shfl(wi, 31, 32); wt_run = __shfl(wti, 31, 32);
+            if (c.first >= 0) { stop = k0 + c.first; k0 += 32; break; }
+            T_run = __shfl(c.T_after, 31, 32);
+        }
+        for (; k0 < sg.n; k0 += 32) {   // behind the stop: zero weight, zero gradients
+            const int k = k0 + lane;
+            if (k < sg.n) {
+                const int64_t s = sg.start + k;
+                p.ws[s] = 0.0f; p.d_sigmas[s] = 0.0f;
+                p.d_rgbs[3 * s] = 0.0f; p.d_rgbs[3 * s + 1] = 0.0f; p.d_rgbs[3 * s + 2] = 0.0f;
+            }
+        }
+        const int n_live = stop >= 0 ? (stop / 32 + 1) * 32 : sg.n;   // passes B and C stop behind the stop sample's chunk
+        aO = half_sum(aO); aD = half_sum(aD); aR = half_sum(aR); aG = half_sum(aG); aB = half_sum(aB);
+        aNx = half_sum(aNx); aNy = half_sum(aNy); aNz = half_sum(aNz);
+        aRo = half_sum(aRo); aPx = half_sum(aPx); aPy = half_sum(aPy); aPz = half_sum(aPz);
+        dacc = half_sum(dacc);
+#pragma unroll
+        for (int cc = 0; cc < CMAX; cc++) aS[cc] = half_sum(aS[cc]);
+        // ---------------- loss terms and gradient seeds of the ray
+        const float e0 = aR - p.gt[3 * r], e1 = aG - p.gt[3 * r + 1], e2 = aB - p.gt[3 * r + 2];
+        const float gR = p.g_rgb * 2.0f * e0, gG = p.g_rgb * 2.0f * e1, gB = p.g_rgb * 2.0f * e2;
+        const float oo = aO + 1e-10f;
+        const float lgo = logf(oo);
+        const float gO = p.g_op * (-lgo - 1.0f);
+        const float gd = p.g_dist;
+        if (lane == 0) {
+            p.total_samples[r] = stop >= 0 ? stop : sg.n;
+            p.opacity[r] = aO; p.depth[r] = aD;
+            p.rgb[3 * r] = aR; p.rgb[3 * r + 1] = aG; p.rgb[3 * r + 2] = aB;
+            p.normal[3 * r] = aNx; p.normal[3 * r + 1] = aNy; p.normal[3 * r + 2] = aNz;
+            p.Ro[r] = aRo; p.Rp[3 * r] = aPx; p.Rp[3 * r + 1] = aPy; p.Rp[3 * r + 2] = aPz;
+#pragma unroll
+            for (int cc = 0; cc < CMAX; cc++)
+                if (cc < p.classes) p.sem[r * p.classes + cc] = aS[cc];
+            s_rgb = e0 * e0 + e1 * e1 + e2 * e2; s_op = -oo * lgo; s_dist = dacc;
+            n_used = (unsigned long long)(stop >= 0 ? stop : sg.n);
+        }
+        const float w_sum = w_run, wt_sum = wt_run;
+        // ---------------- pass B: tot = sum dL_dws ws  (dL_dws of the distortion term, closed form)
+        float tot = 0.0f;
+        if (gd != 0.0f) {
+            float wr = 0, wtr = 0;
+            for (int q0 = 0; q0 < n_live; q0 += 32) {
+                const int k = q0 + lane;
+                const int64_t s = sg.start + k;
+                const bool valid = k < sg.n;
+                const float w = valid ? p.ws[s] : 0.0f, tt = valid ? p.ts[s] : 0.0f, dl = valid ? p.deltas[s] : 0.0f;
+                const float wi = wr + half_incl_scan_add(w, lane);
+                const float wti = wtr + half_incl_scan_add(w * tt, lane);
+                float we = __shfl_up(wi, 1, 32), wte = __shfl_up(wti, 1, 32);
+                if (lane == 0) { we = wr; wte = wtr; }
+                const float dws = gd * 2 * ((tt * we - wte) + (wt_sum - wti - tt * (w_sum - wi))) + gd * 2.0f / 3 * w * dl;
+                tot += dws * w;
+                wr = __shfl(wi, 31, 32); wtr = __shfl(wti, 31, 32);
+            }
+            tot = half_sum(tot);
+        }
+        // ---------------- pass C: composite_train_bw
+        {
+            float T2 = 1.0f, r_run = 0, g_run = 0, b_run = 0, p_run = 0, wr = 0, wtr = 0;
+            for (int q0 = 0; q0 < n_live; q0 += 32) {
+                const int k = q0 + lane;
+                const int64_t s = sg.start + k;
+                const Chunk c = chunk_alpha(p.sigmas, p.deltas, s, k < sg.n, T2, p.T_thr, lane);
+                const float w = c.valid ? c.a * c.T_before : 0.0f;
+                float cr = 0, cg = 0, cb = 0, tt = 0, dl = 0, wsv = 0;
+                if (c.valid) {
+                    cr = p.rgbs[3 * s]; cg = p.rgbs[3 * s + 1]; cb = p.rgbs[3 * s + 2];
+                    tt = p.ts[s]; dl = p.deltas[s]; wsv = p.ws[s];
+                }
+                const float wi = wr + half_incl_scan_add(wsv, lane);
+                const float wti = wtr + half_incl_scan_add(wsv * tt, lane);
+                float we = __shfl_up(wi, 1, 32), wte = __shfl_up(wti, 1, 32);
+                if (lane == 0) { we = wr; wte = wtr; }
+                const float dws = gd != 0.0f ? gd * 2 * ((tt * we - wte) + (wt_sum - wti - tt * (w_sum - wi))) + gd * 2.0f / 3 * wsv * dl
+                                             : 0.0f;
+                const float ri = r_run + half_incl_scan_add(w * cr, lane);
+                const float gi = g_run + half_incl_scan_add(w * cg, lane);
+                const float bi = b_run + half_incl_scan_add(w * cb, lane);
+                const float pi = p_run + half_incl_scan_add(dws * wsv, lane);
+                if (c.valid) {
+                    const float wa = c.active ? w : 0.0f;
+                    p.d_rgbs[3 * s] = gR * wa; p.d_rgbs[3 * s + 1] = gG * wa; p.d_rgbs[3 * s + 2] = gB * wa;
+                    const float T = c.T_after;
+                    const float v = dl * (gR * (cr * T - (aR - ri)) + gG * (cg * T - (aG - gi)) + gB * (cb * T - (aB - bi)) +
+                                          gO * (1 - aO) + T * dws - (tot - pi));
+                    p.d_sigmas[s] = c.active ? v : 0.0f;
+                }
+                if (c.first >= 0) break;
+                T2 = __shfl(c.T_after, 31, 32);
+                r_run = __shfl(ri, 31, 32); g_run = __shfl(gi, 31, 32); b_run = __shfl(bi, 31, 32); p_run = __shfl(pi, 31, 32);
+                wr = __shfl(wi, 31, 32); wtr = __shfl(wti, 31, 32);
+            }
+        }
+    }
+    // ---------------- loss terms of the block's rays: one set of atomics per block
+    const int hw = threadIdx.x >> 5;
+    if ((threadIdx.x & 31) == 0) { part[0][hw] = s_rgb; part[1][hw] = s_op; part[2][hw] = s_dist; part_n[hw] = n_used; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t0 = 0, t1 = 0, t2 = 0;
+        unsigned long long tn = 0;
+        for (int q = 0; q < 8; q++) { t0 += part[0][q]; t1 += part[1][q]; t2 += part[2][q]; tn += part_n[q]; }
+        t0 *= p.g_rgb; t1 *= p.g_op; t2 *= p.g_dist;
+        atomicAdd(p.terms, t0 + t1 + t2);
+        atomicAdd(p.terms + 1, t0);
+        atomicAdd(p.terms + 2, t1);
+        atomicAdd(p.terms + 3, t2);
+        atomicAdd(reinterpret_cast<unsigned long long*>(p.vr_samples), tn);
+    }
+}
+
 // Inputs of RefLoss (rendering.py:243-245): normals_diff = (n_raw - n_pred)^2,
 // normals_ori = max(<n_raw, normalize(dir)>, 0)^2
 __global__ void refloss_inputs_kernel(const float* __restrict__ n_raw, const float* __restrict__ n_pred,
@@ -808,6 +1014,36 @@ int ngp_nerf_loss(const float* rgb, const float* target_rgb, const float* opacit
     hipLaunchKernelGGL(nerf_loss_kernel, dim3(ngp_blocks(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, rgb,
                        target_rgb, opacity, distortion, n_rays, 1.0f / (3.0f * n_rays), lambda_opacity / n_rays,
                        lambda_distortion / n_rays, terms, d_rgb, d_opacity);
+    return ngp_check_launch();
+}
+
+int ngp_render_loss_fused(const float* sigmas, const float* rgbs, const float* dsigma_dx, const float* scale3,
+                          const float* normal_head, int64_t ld_normal, const float* sem_logits, int64_t ld_sem,
+                          const float* dirs, const float* deltas, const float* ts, const int64_t* rays_a,
+                          const float* target_rgb, float T_threshold, int classes, int n_rays, float lambda_opacity,
+                          float lambda_distortion, int64_t* total_samples, int64_t* vr_samples, float* opacity,
+                          float* depth, float* rgb, float* normal_pred, float* sem, float* ws, float* loss_o,
+                          float* loss_p, float* terms, float* dL_dsigmas, float* dL_drgbs, void* stream)
+{
+    if (n_rays < 1 || classes < 0 || classes > 8 || ld_normal < 3 || ld_sem < classes) return NGP_EINVAL;
+    if (!rays_a || !target_rgb || !total_samples || !vr_samples || !opacity || !depth || !rgb || !normal_pred ||
+        (classes && !sem) || !loss_o || !loss_p || !terms) return NGP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (reinterpret_cast<char*>(vr_samples) == reinterpret_cast<char*>(terms) + 4 * sizeof(float)) {   // adjacent: one fill
+        if (hipMemsetAsync(terms, 0, 4 * sizeof(float) + sizeof(int64_t), st) != hipSuccess) return NGP_ELAUNCH;
+    } else {
+        if (hipMemsetAsync(terms, 0, 4 * sizeof(float), st) != hipSuccess) return NGP_ELAUNCH;
+        if (hipMemsetAsync(vr_samples, 0, sizeof(int64_t), st) != hipSuccess) return NGP_ELAUNCH;
+    }
+    RenderLossArgs a;
+    a.sigmas = sigmas; a.rgbs = rgbs; a.dsig_dx = dsigma_dx; a.np_raw = normal_head; a.sem_logits = sem_logits;
+    a.dirs = dirs; a.deltas = deltas; a.ts = ts; a.gt = target_rgb; a.scale3 = scale3; a.rays_a = rays_a;
+    a.ld_np = ld_normal; a.ld_sem = ld_sem; a.T_thr = T_threshold;
+    a.g_rgb = 1.0f / (3.0f * n_rays); a.g_op = lambda_opacity / n_rays; a.g_dist = lambda_distortion / n_rays;
+    a.classes = classes; a.n_rays = n_rays; a.total_samples = total_samples; a.vr_samples = vr_samples;
+    a.opacity = opacity; a.depth = depth; a.rgb = rgb; a.normal = normal_pred; a.sem = sem; a.ws = ws;
+    a.Ro = loss_o; a.Rp = loss_p; a.terms = terms; a.d_sigmas = dL_dsigmas; a.d_rgbs = dL_drgbs;
+    hipLaunchKernelGGL(render_loss_fused_kernel<8>, seg_grid(n_rays), dim3(256), 0, st, a);
     return ngp_check_launch();
 }
 

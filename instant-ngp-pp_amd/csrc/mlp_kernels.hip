@@ -1272,6 +1272,39 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     }
 }
 
+// act_bwd over (n, cols <= 4) rows that also accumulates sum_rows ||dz[row, :]||_2 into *norm_acc (the norm-bound sums of
+// ngp_clip_decide come out of the pass that forms dz2 instead of a launch of their own)
+__global__ void __launch_bounds__(256) act_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ yz,
+                                                           int64_t n, int cols, int act, float* __restrict__ dz,
+                                                           float* __restrict__ norm_acc)
+{
+    __shared__ float part[4];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float acc = 0.0f;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        float q = 0.0f;
+        for (int c = 0; c < cols; c++) {
+            const int64_t i = r * cols + c;
+            const float g = dy ? dy[i] : 1.0f;
+            float v;
+            switch (act) {
+                case NGP_ACT_RELU: v = yz[i] > 0.0f ? g : 0.0f; break;
+                case NGP_ACT_SIGMOID: { const float s = yz[i]; v = g * s * (1.0f - s); } break;
+                case NGP_ACT_SOFTPLUS: v = g * -expm1f(-yz[i]); break;
+                case NGP_ACT_EXP: v = g * yz[i]; break;
+                default: v = g;
+            }
+            dz[i] = v;
+            q = fmaf(v, v, q);
+        }
+        acc += sqrtf(q);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(norm_acc, part[0] + part[1] + part[2] + part[3]);
+}
 
 // derivative of an activation expressed through its OUTPUT y
 
@@ -1523,12 +1556,14 @@ __global__ void __launch_bounds__(1024) clip_decide_kernel(const float* __restri
                                                            const float* __restrict__ w2b, int64_t n2b,
                                                            const float* __restrict__ sumsq_rest, float max_norm,
                                                            float extra_scale, float* __restrict__ coef,
-                                                           int32_t* __restrict__ need_exact)
+                                                           int32_t* __restrict__ need_exact,
+                                                           const float* __restrict__ rest, int64_t n_rest,
+                                                           float* __restrict__ sumsq_out)
 {
-    __shared__ float ws[4][16];
-    const float* ptr[4] = {w1a, w2a, w1b, w2b};
-    const int64_t cnt[4] = {n1a, n2a, n1b, n2b};
-    for (int k = 0; k < 4; k++) {
+    __shared__ float ws[5][16];
+    const float* ptr[5] = {w1a, w2a, w1b, w2b, rest};
+    const int64_t cnt[5] = {n1a, n2a, n1b, n2b, rest ? n_rest : 0};
+    for (int k = 0; k < 5; k++) {
         float q = 0.0f;
         for (int64_t i = threadIdx.x; i < cnt[k]; i += 1024) q = fmaf(ptr[k][i], ptr[k][i], q);
 #pragma unroll
@@ -1543,8 +1578,13 @@ __global__ void __launch_bounds__(1024) clip_decide_kernel(const float* __restri
             for (int w = 0; w < 16; w++) t += ws[k][w];
             f[k] = sqrtf(t);
         }
+        float rest_sq = sumsq_rest ? *sumsq_rest : 0.0f;
+        if (rest) {                       // the exact part summed here (ngp_clip_decide_rest): no launch of its own
+            for (int w = 0; w < 16; w++) rest_sq += ws[4][w];
+            *sumsq_out = rest_sq;         // the conditional exact route (ngp_sumsq_if) continues from it
+        }
         const float ba = f[0] * f[1] * sums[0], bb = f[2] * f[3] * sums[1];
-        const float bound = sqrtf(ba * ba + bb * bb + (sumsq_rest ? *sumsq_rest : 0.0f)) * extra_scale;
+        const float bound = sqrtf(ba * ba + bb * bb + rest_sq) * extra_scale;
         const bool safe = bound * 1.001f + 1e-6f < max_norm;     // false for NaN / inf
         *need_exact = safe ? 0 : 1;
         if (safe) *coef = extra_scale;
@@ -1787,6 +1827,19 @@ int ngp_act_bwd(const float* dy, const float* y_or_z, int64_t count, int activat
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y_or_z, count,
                        activation, dz);
+    return ngp_check_launch();
+}
+
+int ngp_act_bwd_rows(const float* dy, const float* y_or_z, int64_t n, int cols, int activation, float* dz,
+                     float* row_norm_acc, void* stream)
+{
+    if (n < 0 || cols < 1 || cols > 4) return NGP_EINVAL;
+    if (n == 0) return NGP_OK;
+    if (!dz || !row_norm_acc || (activation != NGP_ACT_NONE && !y_or_z)) return NGP_EINVAL;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;      // one atomic per block
+    hipLaunchKernelGGL(act_bwd_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y_or_z, n, cols,
+                       activation, dz, row_norm_acc);
     return ngp_check_launch();
 }
 
@@ -2036,7 +2089,22 @@ int ngp_clip_decide(const float* row_norm_sums, const float* w1_a, int64_t n1_a,
         !need_exact)
         return NGP_EINVAL;
     hipLaunchKernelGGL(clip_decide_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_norm_sums, w1_a, n1_a, w2_a,
-                       n2_a, w1_b, n1_b, w2_b, n2_b, sumsq_rest, max_norm, extra_scale, coef, need_exact);
+                       n2_a, w1_b, n1_b, w2_b, n2_b, sumsq_rest, max_norm, extra_scale, coef, need_exact,
+                       (const float*)nullptr, (int64_t)0, (float*)nullptr);
+    return ngp_check_launch();
+}
+
+int ngp_clip_decide_rest(const float* row_norm_sums, const float* w1_a, int64_t n1_a, const float* w2_a, int64_t n2_a,
+                         const float* w1_b, int64_t n1_b, const float* w2_b, int64_t n2_b, const float* rest,
+                         int64_t n_rest, float* sumsq, float max_norm, float extra_scale, float* coef,
+                         int32_t* need_exact, void* stream)
+{
+    if (!row_norm_sums || !w1_a || !w2_a || !w1_b || !w2_b || n1_a < 1 || n2_a < 1 || n1_b < 1 || n2_b < 1 || !coef ||
+        !need_exact || !rest || n_rest < 0 || !sumsq)
+        return NGP_EINVAL;
+    hipLaunchKernelGGL(clip_decide_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_norm_sums, w1_a, n1_a, w2_a,
+                       n2_a, w1_b, n1_b, w2_b, n2_b, (const float*)sumsq, max_norm, extra_scale, coef, need_exact, rest,
+                       n_rest, sumsq);
     return ngp_check_launch();
 }
 

@@ -133,8 +133,11 @@ class _Mlp2Bwd:
     On the fused route dz1 = act1'(hidden) * (dz2 . W2) is formed inside the two first-layer products."""
 
     def __init__(self, d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, ld_in, n_in, W1, ldw1, dW1, dW2,
-                 db1, db2):
+                 db1, db2, norm_acc=None):
+        """norm_acc: device scalar that takes sum_s ||dz2[s]|| (the trainer's norm-bound sums), accumulated by the pass
+        that forms dz2 when that pass is the elementwise one (self.norm_noted says whether it was)"""
         self.a = (d_out, out, ld_out, act2, W2, hidden, H, act1, n_out, x_in, ld_in, n_in, W1, ldw1, dW1, dW2, db1, db2)
+        self.norm_noted = False
         n = hidden.shape[0]
         dev = hidden.device
         self.n = n
@@ -143,7 +146,11 @@ class _Mlp2Bwd:
         self.dw2_done = False
         if self.fused:
             self.dz2 = torch.empty(n, n_out, dtype=_f32, device=dev)
-            call("act_bwd", d_out, out, n * n_out, act2, self.dz2)
+            if norm_acc is not None and n_out <= 4:
+                call("act_bwd_rows", d_out, out, n, n_out, act2, self.dz2, norm_acc)
+                self.norm_noted = True
+            else:
+                call("act_bwd", d_out, out, n * n_out, act2, self.dz2)
             return
         self.dz2 = torch.empty(n, 16 if n_out > 4 else 4, dtype=_f32, device=dev)
         self.dz1 = torch.empty(n, H, dtype=_f32, device=dev)
@@ -252,7 +259,8 @@ def _bound_note(model, st, slot, n_out, n):
     if not st.fused:
         model._norm_bound_ok = False
         return
-    call("row_norm_sum", st.dz2, n_out, n, n_out, acc[slot:slot + 1])
+    if not st.norm_noted:      # (the elementwise stage adds the sum itself when it is handed the accumulator)
+        call("row_norm_sum", st.dz2, n_out, n, n_out, acc[slot:slot + 1])
     model._norm_bound_hits = getattr(model, "_norm_bound_hits", 0) + 1
 
 
@@ -272,14 +280,14 @@ class _FieldFn(Function):
     def forward(ctx, model, x, d, embed_a, xyz_table, W1, b1, W2, b2, rgb_table, rgb_p, nrm_p, sem_p):
         n = x.shape[0]
         dev = x.device
-        _wait_params(model, rgb_table=False)
         xe, re = model.xyz_encoder, model.rgb_encoder
         C = model.semantic_header.n_output_dims
         E = 0 if embed_a is None else embed_a.shape[1]
         K = 144 + E
         Kp = model.rgb_net.padded_in
         span = model._span()
-        xn = (x - model.xyz_min).div_(span)
+        xn = (x - model.xyz_min).div_(span)   # (before the wait below: it reads no parameter and runs under the Adam sweep)
+        _wait_params(model, rgb_table=False)
         # Samples behind their ray's early-termination point take no part in the image and get no gradient: when the
         # renderer hands over the rays' segments (model._live_ctx), the colour branch and its backward run on the
         # live samples only.  The density head needs every sample (the stop depends on sigma); the list of live rows
@@ -537,8 +545,10 @@ class _FieldFn(Function):
         if d_rgb is not None:
             acc_rgbp, g_rgbp = grad_buffer("rgb_p", rgb_p)
             dfeat_rgb = torch.empty(n, W_cols, dtype=_f32, device=dev)
+            nb_acc = getattr(model, "_norm_bound_acc", None)
             st = _Mlp2Bwd(d_rgb.contiguous(), rgb_o, 3, model.rgb_net.output_activation, rgb_p[128 * Kp:], a_r, 128,
-                          _RELU, 3, rgb_in, Kp, Kp, rgb_p, Kp, acc_rgbp, acc_rgbp[128 * Kp:], None, None)
+                          _RELU, 3, rgb_in, Kp, Kp, rgb_p, Kp, acc_rgbp, acc_rgbp[128 * Kp:], None, None,
+                          norm_acc=None if nb_acc is None else nb_acc[0:1])
             st.input_product(dfeat_rgb, W_cols, W_cols, 16, False)
             stages.append(st)
             rgb_stage = st
@@ -590,8 +600,10 @@ class _FieldFn(Function):
         if d_sig is not None:
             (acc_W1, g_W1), (acc_W2, g_W2) = grad_buffer("W1", W1), grad_buffer("W2", W2)
             (acc_b1, g_b1), (acc_b2, g_b2) = grad_buffer("b1", (128,)), grad_buffer("b2", (1,))
+            nb_acc = getattr(model, "_norm_bound_acc", None)
             st = _Mlp2Bwd(d_sig.contiguous().view(n, 1), sig, 1, _SOFTPLUS, W2, a1, 128, _SOFTPLUS, 1,
-                          feat, 128, 128, W1, 128, acc_W1, acc_W2, acc_b1, acc_b2)
+                          feat, 128, 128, W1, 128, acc_W1, acc_W2, acc_b1, acc_b2,
+                          norm_acc=None if nb_acc is None else nb_acc[1:2])
             if not reuse:
                 dfeat = torch.empty(n, 128, dtype=_f32, device=dev)
                 st.input_product(dfeat, 128, 128, 0, False)

@@ -315,6 +315,9 @@ def _render_rays_train(model, rays_o, rays_d, hits_t, **kwargs):
             kwargs[k] = torch.repeat_interleave(v[rays_a[:, 0]], rays_a[:, 2], 0, output_size=xyzs.shape[0])
     # the rays' segments go along: the field evaluates its colour branch only on the samples the compositor below
     # will use (all up to a ray's early-termination point — same sigma, deltas and T_threshold, same decision)
+    fused = kwargs.pop('_fused_loss', None)
+    if fused is not None and _fused_tail_ok(model, kwargs, exp_step_factor, classes):
+        return _render_loss_fused(model, results, xyzs, dirs, rays_a, T_threshold, classes, fused, kwargs)
     model._live_ctx = (rays_a, results['deltas'], T_threshold)
     try:
         sigmas, rgbs, normals_raw, normals_pred, sems = model(xyzs, dirs, **kwargs)
@@ -344,6 +347,65 @@ def _render_rays_train(model, rays_o, rays_d, hits_t, **kwargs):
     # NeRFLoss(normal_ref=True) needs Ro to reach the density field through normals_raw (reference:
     # create_graph=True, networks.py:186-196); the default field returns detached analytic normals
     results['Ro']._ngp_normals_have_grad = bool(normals_raw.requires_grad)
+    return results
+
+
+def _fused_tail_ok(model, kwargs, exp_step_factor, classes):
+    """the one-launch render + loss tail covers the default recipe: sigmoid colours (no tone mapper), black background,
+    detached analytic normals, at most 8 classes"""
+    return (getattr(model, 'rgb_act', 'Sigmoid') == 'Sigmoid' and not kwargs.get('use_skybox', False)
+            and not (exp_step_factor != 0 and kwargs.get('random_bg', False))
+            and not getattr(model, 'differentiable_normals', False) and classes <= 8
+            and not getattr(model, 'compact_dead_samples', None) and hasattr(model, '_field'))
+
+
+class _RenderLossFn(torch.autograd.Function):
+    """Default-recipe tail of a training step as ONE launch (ngp_render_loss_fused): normals, softmax, compositing,
+    Ref-NeRF regularisers, distortion loss, NeRFLoss's default terms AND their gradients w.r.t. the field's outputs.
+    forward returns (terms (4) = [loss, rgb, opacity, distortion], per-ray results ..., ws); only terms is
+    differentiable, and only through terms[0] with a unit seed (NGPTrainer's use): backward hands the gradients
+    computed in forward to the field."""
+
+    @staticmethod
+    def forward(ctx, sig, rgb_o, dsig_dx, np_raw, sem_logits, dirs, deltas, ts, rays_a, rgb_gt, scale3, T_thr, classes,
+                lambda_opa, lambda_dist):
+        n, nr = sig.shape[0], rays_a.shape[0]
+        dev = sig.device
+        f32 = torch.float32
+        total = torch.empty(nr, dtype=torch.int64, device=dev)
+        E = lambda *shape: torch.empty(*shape, dtype=f32, device=dev)   # (the caching allocator launches nothing)
+        opacity, depth, rgb, normal, Ro, Rp, sem = E(nr), E(nr), E(nr, 3), E(nr, 3), E(nr), E(nr, 3), E(nr, classes)
+        ws, d_sig, d_rgb = E(n), E(n), E(n, 3)
+        acc = E(8)                                   # [terms (4) | vr_samples (int64) | -]: adjacent, cleared by one memset
+        terms, vr = acc[:4], acc[4:6].view(torch.int64)
+        call("render_loss_fused", sig, rgb_o, dsig_dx, scale3, np_raw, np_raw.stride(0), sem_logits, sem_logits.stride(0),
+             dirs, deltas, ts, rays_a, rgb_gt, float(T_thr), int(classes), nr, float(lambda_opa), float(lambda_dist),
+             total, vr, opacity, depth, rgb, normal, sem, ws, Ro, Rp, terms, d_sig, d_rgb)
+        ctx.save_for_backward(d_sig, d_rgb)
+        ctx.set_materialize_grads(False)             # no zero-filled gradient tensors for the ten other outputs
+        ctx.mark_non_differentiable(total, vr, opacity, depth, rgb, normal, sem, ws, Ro, Rp)
+        return terms, total, vr, opacity, depth, rgb, normal, sem, ws, Ro, Rp
+
+    @staticmethod
+    def backward(ctx, g_terms, *_unused):
+        d_sig, d_rgb = ctx.saved_tensors
+        return (d_sig, d_rgb) + (None,) * 13
+
+
+def _render_loss_fused(model, results, xyzs, dirs, rays_a, T_threshold, classes, fused, kwargs):
+    sig, rgb_o, dsig_dx, np_raw, sem_logits = model._field(xyzs, dirs, kwargs)
+    rgb_gt, lambda_opa, lambda_dist = fused
+    (terms, total, vr, opacity, depth, rgb, normal, sem, ws, Ro, Rp) = _RenderLossFn.apply(
+        sig, rgb_o, dsig_dx, np_raw, sem_logits, dirs.contiguous(), results['deltas'], results['ts'], rays_a,
+        rgb_gt.contiguous(), model._inv_span(), T_threshold, classes, lambda_opa, lambda_dist)
+    results['sigma'] = sig
+    results['xyzs'] = xyzs
+    results['vr_samples'] = vr[0]
+    results['opacity'], results['depth'], results['rgb'] = opacity, depth, rgb
+    results['normal_pred'], results['semantic'], results['ws'] = normal, sem, ws
+    results['Ro'], results['Rp'] = Ro, Rp
+    results['Ro']._ngp_normals_have_grad = False
+    results['_loss_terms'] = terms        # terms[0] carries the graph: NGPTrainer seeds its backward with 1
     return results
 
 

@@ -177,6 +177,8 @@ class NGPTrainer:
         self.loss_kwargs = dict(loss_kwargs or {})
         optional = any(self.loss_kwargs.get(k) for k in ("normal_ref", "normal_mono", "semantic", "depth_mono", "embed_msk"))
         self.fused_loss = not optional   # default recipe (rgb + opacity + distortion); False -> NeRFLoss module
+        # NGP_NO_FUSED_TAIL=1 (A/B): the launch-per-operation tail (normals, softmax, compositor, RefLoss, distortion, loss)
+        self.fused_tail = os.environ.get("NGP_NO_FUSED_TAIL", "0") != "1" 
         if self.loss_kwargs.get("normal_ref"):
             model.differentiable_normals = True
         self.warmup_steps = 256
@@ -277,6 +279,12 @@ class NGPTrainer:
         self._norm_share_armed = False   # step() arms it: exactly one backward per optimizer step
         self._norm_share_fired = 0
 
+    def _unit_seed(self, terms):
+        s = getattr(self, '_seed4', None)
+        if s is None or s.device != terms.device:
+            s = self._seed4 = torch.tensor([1.0, 0.0, 0.0, 0.0], device=terms.device)
+        return s
+
     def _early_norm_share(self):
         if self._norm_share_armed and not self._bound_step:
             self._norm_share_fired += 1
@@ -320,8 +328,13 @@ class NGPTrainer:
                 ahead.launch(model, next_rays[0], next_rays[1], self.exp_step_factor)
         elif ahead is not None:
             marched = ahead.take(rays_o, rays_d, self.exp_step_factor)
+        default_recipe = bool(self.fused_loss and not loss_kwargs and not target)
+        extra = {}
+        if default_recipe and self.fused_tail and rays_o.is_cuda:
+            # render + loss + the loss's gradients as one launch behind the field (rendering._RenderLossFn)
+            extra['_fused_loss'] = (rgb_gt, self.loss_fn.lambda_opa, self.loss_fn.lambda_distortion)
         results = render(model, rays_o, rays_d, exp_step_factor=self.exp_step_factor,
-                         num_classes=self.num_classes, marched=marched, **self.render_kwargs)
+                         num_classes=self.num_classes, marched=marched, **self.render_kwargs, **extra)
         self._norm_share_armed, self._norm_share_fired = True, 0   # one backward follows, then the optimizer step
         # clip_grad_norm_(50) from an upper bound of the norm (ngp_clip_decide) instead of the 0.8 GB sum-of-squares
         # pass: only on the default recipe, where the fused field backward is the one writer of the table gradients
@@ -331,7 +344,11 @@ class NGPTrainer:
         model._norm_bound_hits, model._norm_bound_ok = 0, True
         if self.norm_bound:
             model.rgb_encoder._bound_valid = model.xyz_encoder._bound_valid = True
-        if self.fused_loss and not loss_kwargs and not target:
+        if '_loss_terms' in results:
+            terms = results.pop('_loss_terms')
+            loss = terms[0]
+            torch.autograd.backward([terms], [self._unit_seed(terms)])
+        elif self.fused_loss and not loss_kwargs and not target:
             # same value and gradients as sum(term.mean()) over NeRFLoss's default terms; the
             # gradients are seeded directly (no loss node, no multiplications by 1)
             terms, (d_rgb, d_op, d_ws) = nerf_loss_and_grads(
@@ -381,10 +398,10 @@ class NGPTrainer:
                     lo = self._mlp_lo
                     Kp = m.rgb_net.padded_in
                     rgb_p, lin1, lin2 = m.rgb_net.params, m.xyz_net[0], m.xyz_net[2]
-                    call("sumsq", self.flat_grad[lo:n], n - lo, self.scalars[0:1])            # MLP gradients: exact
-                    call("clip_decide", self.norm_acc, rgb_p, 128 * Kp, rgb_p[128 * Kp:], rgb_p.numel() - 128 * Kp,
-                         lin1.weight, lin1.weight.numel(), lin2.weight, lin2.weight.numel(), self.scalars[0:1],
-                         float(self.clip_norm), 1.0, self.scalars[1:2], self.need_exact)
+                    # (the MLP gradients' exact sum of squares is formed by the same launch, into scalars[0])
+                    call("clip_decide_rest", self.norm_acc, rgb_p, 128 * Kp, rgb_p[128 * Kp:], rgb_p.numel() - 128 * Kp,
+                         lin1.weight, lin1.weight.numel(), lin2.weight, lin2.weight.numel(), self.flat_grad[lo:n], n - lo,
+                         self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2], self.need_exact)
                     # bound >= clip_norm (not seen in training): the exact norm after all, decided on the device
                     call("sumsq_if", self.flat_grad[0:lo], lo, self.scalars[0:1], self.need_exact)
                     call("clip_coef_if", self.scalars[0:1], float(self.clip_norm), 1.0, self.scalars[1:2], self.need_exact)

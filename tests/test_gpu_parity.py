@@ -1458,9 +1458,12 @@ def test_render_matches_reference_render_golden(ngp, golden, monkeypatch):
 G8_BAR, G10_BAR = 3e-4, 5e-5
 
 
-@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("compact", [False, True, "fused_tail"])
 def test_training_step_matches_reference_golden(ngp, golden, monkeypatch, compact):
-    """(compact: the same step with the colour branch on the live samples only, model.compact_dead_samples.)
+    """(compact: the same step with the colour branch on the live samples only, model.compact_dead_samples;
+    "fused_tail": normals, softmax, compositor, RefLoss, distortion, loss and the compositor's backward as ONE launch,
+    ngp_render_loss_fused — the trainer's default route — with every per-ray result compared against the
+    launch-per-operation route on the same samples.)
     One whole training step against the G8 fixture — the reference's OWN render() -> NeRFLoss
     (losses.py) -> sum of term means -> backward through its autograd Functions -> clip_grad_norm_(50)
     -> torch.optim.Adam(lr=1e-2, eps=1e-8).step(), run on the CPU (tinycudann = pure-torch stand-in,
@@ -1482,19 +1485,37 @@ def test_training_step_matches_reference_golden(ngp, golden, monkeypatch, compac
             named[k].copy_(T(g[k]))
         model.density_bitfield.copy_(T(g["density_bitfield"]))
     tr = NGPTrainer(model, lr=1e-2)                 # flat parameter / gradient / Adam-state buffers
-    model.compact_dead_samples = compact
+    fused_tail = compact == "fused_tail"
+    model.compact_dead_samples = bool(compact) and not fused_tail
     named = dict(model.named_parameters())
     o, d, gt = T(g["rays_o"]), T(g["rays_d"]), T(g["rgb_gt"])
     noise = T(g["noise"])
     monkeypatch.setattr(torch, "rand_like", lambda t, *a, **k: noise.clone())
-    res = render(model, o, d, exp_step_factor=0.0, num_classes=7)
+    if fused_tail:
+        with torch.no_grad():
+            ref_res = render(model, o, d, exp_step_factor=0.0, num_classes=7)
+        res = render(model, o, d, exp_step_factor=0.0, num_classes=7,
+                     _fused_loss=(gt, tr.loss_fn.lambda_opa, tr.loss_fn.lambda_distortion))
+    else:
+        res = render(model, o, d, exp_step_factor=0.0, num_classes=7)
     monkeypatch.undo()
-    terms, (d_rgb, d_op, d_ws) = nerf_loss_and_grads(res["rgb"], res["opacity"], res["ws"], res["deltas"], res["ts"],
-                                                    res["rays_a"], gt, tr.loss_fn.lambda_opa, tr.loss_fn.lambda_distortion)
-    terms = N(terms)
+    if fused_tail:
+        assert "_loss_terms" in res, "the one-launch tail was not taken"
+        for k in ("opacity", "depth", "rgb", "normal_pred", "semantic", "ws", "Ro", "Rp"):
+            close(N(res[k]), N(ref_res[k]), 2e-5, 2e-6)
+        assert torch.equal(res["rays_a"], ref_res["rays_a"]) and int(res["vr_samples"]) == int(ref_res["vr_samples"])
+        terms_t = res.pop("_loss_terms")
+        terms = N(terms_t)
+    else:
+        terms_t, (d_rgb, d_op, d_ws) = nerf_loss_and_grads(res["rgb"], res["opacity"], res["ws"], res["deltas"], res["ts"],
+                                                          res["rays_a"], gt, tr.loss_fn.lambda_opa, tr.loss_fn.lambda_distortion)
+        terms = N(terms_t)
     for i, k in enumerate(("loss", "loss_rgb", "loss_opacity", "loss_distortion")):
         assert abs(terms[i] - float(g[k])) <= 2e-4 * abs(float(g[k])) + 1e-9, (k, terms[i], float(g[k]))
-    torch.autograd.backward([res["rgb"], res["opacity"], res["ws"]], [d_rgb, d_op, d_ws])
+    if fused_tail:
+        torch.autograd.backward([terms_t], [torch.tensor([1.0, 0.0, 0.0, 0.0], device=DEV)])
+    else:
+        torch.autograd.backward([res["rgb"], res["opacity"], res["ws"]], [d_rgb, d_op, d_ws])
     torch.cuda.synchronize()
 
     def rel(a, b):
@@ -2318,6 +2339,35 @@ def test_clip_decide_and_conditional_norm(ngp):
             want_c = scale
             assert float(sums) == np.float32(rest)
         assert abs(float(coef) - want_c) <= 1e-5 * want_c, (float(coef), want_c)
+    # ngp_clip_decide_rest: the exact part (here 40,001 "MLP gradients") is summed by the decision launch itself
+    restv = T((g.normal(size=40001) * 0.01).astype(np.float32))
+    rest_sq = float((N(restv).astype(np.float64) ** 2).sum())
+    for sa, sb, max_norm in ((3.0 / fa, 4.0 / fb, 50.0), (30.0 / fa, 40.0 / fb, 50.0)):
+        sums = torch.zeros(1, device=DEV)
+        coef = torch.full((1,), -7.0, device=DEV)
+        flag = torch.full((1,), 5, dtype=torch.int32, device=DEV)
+        call("clip_decide_rest", T(np.array([sa, sb], np.float32)), w1a, w1a.numel(), w2a, w2a.numel(), w1b, w1b.numel(), w2b,
+             w2b.numel(), restv, restv.numel(), sums, max_norm, 1.0, coef, flag)
+        torch.cuda.synchronize()
+        bound = np.sqrt((fa * sa) ** 2 + (fb * sb) ** 2 + rest_sq)
+        assert int(flag) == (0 if bound * 1.001 + 1e-6 < max_norm else 1)
+        assert abs(float(sums) - rest_sq) < 1e-4 * rest_sq
+    # ngp_act_bwd_rows = ngp_act_bwd + the row-norm sum of its result
+    y = T(g.random((70001, 3)).astype(np.float32))
+    dy = T(g.normal(size=(70001, 3)).astype(np.float32))
+    dz_a, dz_b = torch.empty_like(y), torch.empty_like(y)
+    acc = torch.zeros(1, device=DEV)
+    call("act_bwd", dy, y, y.numel(), 2, dz_a)                   # NGP_ACT_SIGMOID
+    call("act_bwd_rows", dy, y, y.shape[0], 3, 2, dz_b, acc)
+    assert torch.equal(dz_a, dz_b)
+    want = np.sqrt((N(dz_a).astype(np.float64) ** 2).sum(1)).sum()
+    assert abs(float(acc) - want) < 1e-5 * want
+    acc.zero_()
+    sig = T(g.random(5003).astype(np.float32) * 3)
+    dz1 = torch.empty_like(sig)
+    call("act_bwd_rows", None, sig, sig.numel(), 1, 3, dz1, acc)   # softplus through its output, unit upstream gradient
+    want = np.abs(-np.expm1(-N(sig).astype(np.float64))).sum()
+    assert abs(float(acc) - want) < 1e-5 * want
 
 
 def test_trainer_norm_bound_route_matches_exact_route(ngp):
