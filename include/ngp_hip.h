@@ -166,6 +166,34 @@ int ngp_composite_test_fw(const float* sigmas, const float* rgbs, const float* n
                           float* opacity, float* depth, float* rgb, float* normal,
                           float* normal_raw, float* sem, void* stream);
 
+/* Device-driven rounds of the same loop (rendering.py:46-133): the number of alive rays, the samples per ray of the round
+ * (N_samples = max(min(N_rays // N_alive, 64), min_samples)), the running `samples` sum of the loop head and the
+ * total sample count live in a device record, so the host enqueues round after round without reading anything back.
+ *   state int32[8]: [0] n_alive (caller sets it to n_rays, the rest to 0)  [1] N_samples of the round
+ *                   [2] sum of N_samples so far  [3] done (no alive ray left, or the sum reached max_samples_total)
+ *                   [4] rounds begun  [5] n_alive behind the last compaction (adopted by the next round's head)
+ *                   [6:8] int64 total samples marched
+ * ngp_test_round_begin      evaluates the loop head into state;
+ * ngp_raymarching_test_rounds / ngp_composite_test_fw_rounds  = the two kernels above with (n_alive, n_samples) read from
+ *                           state; launched for n_alive_bound >= n_alive rays (a stale host copy of the count is a
+ *                           valid bound: it only decreases); outputs laid out (n_alive, N_samples, .) as above;
+ * ngp_alive_compact         alive_out = alive_in[alive_in >= 0] in order (rendering.py:115), state[5] = its length;
+ *                           block_counts: scratch of ceil(n_alive_bound / 1024) int32.
+ * All of them do nothing once state[3] is set.  The caller zero-fills xyzs / dirs per round (padding rows are evaluated by
+ * the field) up to its own bound on n_alive * N_samples. */
+int ngp_test_round_begin(int32_t* state, int n_rays, int min_samples, int max_samples_total, void* stream);
+int ngp_raymarching_test_rounds(const float* rays_o, const float* rays_d, float* hits_t, const int64_t* alive_indices,
+                                const uint8_t* density_bitfield, int cascades, float scale, float exp_step_factor,
+                                int grid_size, int max_samples, int32_t* state, int n_alive_bound, float* xyzs,
+                                float* dirs, float* deltas, float* ts, int32_t* n_eff_samples, void* stream);
+int ngp_composite_test_fw_rounds(const float* sigmas, const float* rgbs, const float* normals, const float* normals_raw,
+                                 const float* sems, const float* deltas, const float* ts, int64_t* alive_indices,
+                                 float T_threshold, int classes, const int32_t* n_eff_samples, const int32_t* state,
+                                 int n_alive_bound, float* opacity, float* depth, float* rgb, float* normal,
+                                 float* normal_raw, float* sem, void* stream);
+int ngp_alive_compact(const int64_t* alive_in, int32_t* state, int n_alive_bound, int32_t* block_counts,
+                      int64_t* alive_out, void* stream);
+
 /* ------------------------------------------------------------------------
  * V1/V2  training compositor
  * replaces vren.composite_alpha_fw (binding.cpp:166-180, volumerendering.cu:5-63)

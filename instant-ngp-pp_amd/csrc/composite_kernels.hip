@@ -266,8 +266,13 @@ __global__ void composite_test_fw_kernel(const float* __restrict__ sigmas, const
                                          int classes, const int32_t* __restrict__ n_eff, int n_alive, int n_samples,
                                          float* __restrict__ opacity, float* __restrict__ depth,
                                          float* __restrict__ rgb, float* __restrict__ normal,
-                                         float* __restrict__ normal_raw, float* __restrict__ sem)
+                                         float* __restrict__ normal_raw, float* __restrict__ sem,
+                                         const int32_t* __restrict__ state)
 {
+    if (state) {   // device-driven rounds: sizes from ngp_test_round_begin's state
+        if (state[3]) return;
+        n_alive = state[0]; n_samples = state[1];
+    }
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_alive) return;
     const int ne = n_eff[n];
@@ -950,7 +955,24 @@ int ngp_composite_test_fw(const float* sigmas, const float* rgbs, const float* n
         !opacity || !depth || !rgb || !normal || !normal_raw || (classes && (!sem || !sems))) return NGP_EINVAL;
     hipLaunchKernelGGL(composite_test_fw_kernel, dim3(ngp_blocks(n_alive, 64)), dim3(64), 0, (hipStream_t)stream,
                        sigmas, rgbs, normals, normals_raw, sems, deltas, ts, alive_indices, T_threshold, classes,
-                       n_eff_samples, n_alive, n_samples, opacity, depth, rgb, normal, normal_raw, sem);
+                       n_eff_samples, n_alive, n_samples, opacity, depth, rgb, normal, normal_raw, sem,
+                       (const int32_t*)nullptr);
+    return ngp_check_launch();
+}
+
+int ngp_composite_test_fw_rounds(const float* sigmas, const float* rgbs, const float* normals, const float* normals_raw,
+                                 const float* sems, const float* deltas, const float* ts, int64_t* alive_indices,
+                                 float T_threshold, int classes, const int32_t* n_eff_samples, const int32_t* state,
+                                 int n_alive_bound, float* opacity, float* depth, float* rgb, float* normal,
+                                 float* normal_raw, float* sem, void* stream)
+{
+    if (n_alive_bound < 0 || classes < 0 || !state) return NGP_EINVAL;
+    if (n_alive_bound == 0) return NGP_OK;
+    if (!sigmas || !rgbs || !normals || !normals_raw || !deltas || !ts || !alive_indices || !n_eff_samples ||
+        !opacity || !depth || !rgb || !normal || !normal_raw || (classes && (!sem || !sems))) return NGP_EINVAL;
+    hipLaunchKernelGGL(composite_test_fw_kernel, dim3(ngp_blocks(n_alive_bound, 64)), dim3(64), 0, (hipStream_t)stream,
+                       sigmas, rgbs, normals, normals_raw, sems, deltas, ts, alive_indices, T_threshold, classes,
+                       n_eff_samples, 0, 0, opacity, depth, rgb, normal, normal_raw, sem, state);
     return ngp_check_launch();
 }
 

@@ -714,8 +714,13 @@ __global__ void march_test_kernel(const float* __restrict__ rays_o, const float*
                                   const uint8_t* __restrict__ bits, int cascades, float scale, float esf,
                                   int G, int max_samples, int n_samples, int n_alive,
                                   float* __restrict__ xyzs, float* __restrict__ dirs,
-                                  float* __restrict__ deltas, float* __restrict__ ts, int32_t* __restrict__ n_eff)
+                                  float* __restrict__ deltas, float* __restrict__ ts, int32_t* __restrict__ n_eff,
+                                  int32_t* __restrict__ state)
 {
+    if (state) {   // device-driven rounds (ngp_test_round_begin): the round's sizes live on the device
+        if (state[3]) return;
+        n_alive = state[0]; n_samples = state[1];
+    }
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_alive) return;
     const size_t r = (size_t)alive[n];
@@ -740,6 +745,94 @@ __global__ void march_test_kernel(const float* __restrict__ rays_o, const float*
     }
     if (s > 0) hits_t[2 * r] = t_resume;
     n_eff[n] = s;
+    if (state && s > 0)   // total_samples += N_eff_samples.sum() (rendering.py:77)
+        atomicAdd(reinterpret_cast<unsigned long long*>(state + 6), (unsigned long long)s);
+}
+
+// ---- device-driven test-time rounds (rendering.py:46-133 without a host round trip per round) ----------------------
+// state (int32[8]): [0] n_alive  [1] samples per ray of this round  [2] sum of [1] over the rounds so far  [3] done
+//                   [4] rounds begun  [5] n_alive after the last compaction  [6:8] int64 total samples.
+// The loop head `while samples < max_samples: if N_alive == 0: break; N_samples = max(min(N_rays // N_alive, 64), min)`
+__global__ void test_round_begin_kernel(int32_t* __restrict__ state, int n_rays, int min_samples, int max_total)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0 || state[3]) return;
+    const int n_alive = state[4] == 0 ? state[0] : state[5];   // [5]: the count ngp_alive_compact left behind the last round
+    state[0] = n_alive;
+    if (n_alive <= 0 || state[2] >= max_total) { state[3] = 1; state[1] = 0; return; }
+    int ns = n_rays / n_alive;
+    ns = ns < 64 ? ns : 64;
+    ns = ns > min_samples ? ns : min_samples;
+    state[1] = ns;
+    state[2] += ns;
+    state[4] += 1;
+}
+
+// alive_out = alive_in[alive_in >= 0] over the first state[0] entries, order kept (rendering.py:115); two launches:
+// survivors per block of 1024, then every block sums the counts in front of it and writes its own survivors.
+__global__ void __launch_bounds__(1024) alive_count_kernel(const int64_t* __restrict__ alive, const int32_t* __restrict__ state,
+                                                            int32_t* __restrict__ counts)
+{
+    __shared__ int part[16];
+    const int n_alive = state[3] ? 0 : state[0];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const bool keep = i < n_alive && alive[i] >= 0;
+    const int c = __popcll(__ballot(keep));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int q = 0; q < 16; q++) t += part[q];
+        counts[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(1024) alive_write_kernel(const int64_t* __restrict__ alive, int32_t* __restrict__ state,
+                                                            const int32_t* __restrict__ counts, int n_blocks,
+                                                            int64_t* __restrict__ alive_out)
+{
+    __shared__ int part[16];
+    __shared__ int base_s;
+    if (state[3]) return;
+    const int n_alive = state[0];
+    // survivors in front of this block (n_blocks <= a few hundred: one strided pass)
+    int before = 0, total = 0;
+    for (int b = threadIdx.x; b < n_blocks; b += 1024) {
+        const int c = counts[b];
+        total += c;
+        if (b < (int)blockIdx.x) before += c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); total += __shfl_xor(total, o, 64); }
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = before; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int q = 0; q < 16; q++) t += part[q];
+        base_s = t;
+    }
+    __syncthreads();
+    // (total over all waves, for the new n_alive: same reduction once more)
+    __shared__ int tot_part[16];
+    if ((threadIdx.x & 63) == 0) tot_part[threadIdx.x >> 6] = total;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const bool keep = i < n_alive && alive[i] >= 0;
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int wcount[16];
+    if (lane == 0) wcount[wave] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int q = 0; q < wave; q++) off += wcount[q];
+    if (keep) alive_out[off + __popcll(m & ((1ull << lane) - 1ull))] = alive[i];
+    if (blockIdx.x == gridDim.x - 1) {
+        __syncthreads();    // (every thread of the block reaches this: no early exit above for this block)
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int q = 0; q < 16; q++) t += tot_part[q];
+            state[5] = t;   // NOT state[0]: blocks of this launch that start later still read the old count from it;
+                            // ngp_test_round_begin adopts [5] at the head of the next round
+        }
+    }
 }
 
 } // namespace
@@ -963,7 +1056,44 @@ int ngp_raymarching_test(const float* rays_o, const float* rays_d, float* hits_t
         !n_eff_samples) return NGP_EINVAL;
     hipLaunchKernelGGL(march_test_kernel, dim3(ngp_blocks(n_alive, 64)), dim3(64), 0, (hipStream_t)stream,
                        rays_o, rays_d, hits_t, alive_indices, density_bitfield, cascades, scale, exp_step_factor,
-                       grid_size, max_samples, n_samples, n_alive, xyzs, dirs, deltas, ts, n_eff_samples);
+                       grid_size, max_samples, n_samples, n_alive, xyzs, dirs, deltas, ts, n_eff_samples,
+                       (int32_t*)nullptr);
+    return ngp_check_launch();
+}
+
+int ngp_test_round_begin(int32_t* state, int n_rays, int min_samples, int max_samples_total, void* stream)
+{
+    if (!state || n_rays < 1 || min_samples < 1 || max_samples_total < 1) return NGP_EINVAL;
+    hipLaunchKernelGGL(test_round_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, n_rays, min_samples,
+                       max_samples_total);
+    return ngp_check_launch();
+}
+
+int ngp_raymarching_test_rounds(const float* rays_o, const float* rays_d, float* hits_t, const int64_t* alive_indices,
+                                const uint8_t* density_bitfield, int cascades, float scale, float exp_step_factor,
+                                int grid_size, int max_samples, int32_t* state, int n_alive_bound, float* xyzs,
+                                float* dirs, float* deltas, float* ts, int32_t* n_eff_samples, void* stream)
+{
+    if (n_alive_bound < 0 || cascades < 1 || grid_size < 1 || grid_size > 1024 || !state) return NGP_EINVAL;
+    if (n_alive_bound == 0) return NGP_OK;
+    if (!rays_o || !rays_d || !hits_t || !alive_indices || !density_bitfield || !xyzs || !dirs || !deltas || !ts ||
+        !n_eff_samples) return NGP_EINVAL;
+    hipLaunchKernelGGL(march_test_kernel, dim3(ngp_blocks(n_alive_bound, 64)), dim3(64), 0, (hipStream_t)stream,
+                       rays_o, rays_d, hits_t, alive_indices, density_bitfield, cascades, scale, exp_step_factor,
+                       grid_size, max_samples, 0, 0, xyzs, dirs, deltas, ts, n_eff_samples, state);
+    return ngp_check_launch();
+}
+
+int ngp_alive_compact(const int64_t* alive_in, int32_t* state, int n_alive_bound, int32_t* block_counts,
+                      int64_t* alive_out, void* stream)
+{
+    if (n_alive_bound < 0 || !state) return NGP_EINVAL;
+    if (n_alive_bound == 0) return NGP_OK;
+    if (!alive_in || !block_counts || !alive_out) return NGP_EINVAL;
+    const int blocks = (int)ngp_blocks(n_alive_bound, 1024);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(alive_count_kernel, dim3(blocks), dim3(1024), 0, st, alive_in, state, block_counts);
+    hipLaunchKernelGGL(alive_write_kernel, dim3(blocks), dim3(1024), 0, st, alive_in, state, block_counts, blocks, alive_out);
     return ngp_check_launch();
 }
 

@@ -147,6 +147,12 @@ def render_dense(model, rays_o, rays_d, z_vals, **kwargs):
 import os as _os
 
 _REFERENCE_TEST_LOOP = _os.environ.get("NGP_REFERENCE_TEST_LOOP", "0") == "1"
+# NGP_DEVICE_ROUNDS=1 / render(..., device_rounds=True): loop head, alive compaction and sample count on the device, no
+# host round trip per round (volume_render_device_rounds).  Off by default: an 800x800 frame is 34 rounds of ~1.7 ms of
+# field kernels each (tools/rounds_probe.py), the one host sync per round costs ~2 % of the frame, and without the exact
+# row count on the host the field evaluates up to N_rays rows per round instead of N_alive * N_samples (measured 61.6 ms
+# per frame against 55.3 for the host-driven loop).
+_DEVICE_ROUNDS = _os.environ.get("NGP_DEVICE_ROUNDS", "0") == "1"
 
 
 def volume_render(model, rays_o, rays_d, hits_t, opacity, depth, rgb, normal_pred, normal_raw, sem, **kwargs):
@@ -164,6 +170,9 @@ def volume_render(model, rays_o, rays_d, hits_t, opacity, depth, rgb, normal_pre
     if _REFERENCE_TEST_LOOP or kwargs.get('reference_test_loop', False):
         return volume_render_reference(model, rays_o, rays_d, hits_t, opacity, depth, rgb, normal_pred, normal_raw,
                                        sem, **kwargs)
+    if (_DEVICE_ROUNDS or kwargs.get('device_rounds', False)) and rays_o.is_cuda and len(rays_o) > 0:
+        return volume_render_device_rounds(model, rays_o, rays_d, hits_t, opacity, depth, rgb, normal_pred, normal_raw,
+                                           sem, **kwargs)
     N_rays = len(rays_o)
     device = rays_o.device
     exp_step_factor = kwargs.get('exp_step_factor', 0.)
@@ -196,6 +205,72 @@ def volume_render(model, rays_o, rays_d, hits_t, opacity, depth, rgb, normal_pre
              int(classes), N_eff_samples, N_alive, int(N_samples), opacity, depth, rgb, normal_pred, normal_raw, sem)
         alive_indices = alive_indices[alive_indices >= 0]   # the one host sync of the round
 
+    if kwargs.get('use_skybox', False):
+        rgb_bg = model.forward_skybox(rays_d)
+        rgb += rgb_bg * (1 - opacity)[:, None]
+    return total_samples
+
+
+_ROUND_LAG = 3      # rounds the host may be ahead of the device's round state
+
+
+def volume_render_device_rounds(model, rays_o, rays_d, hits_t, opacity, depth, rgb, normal_pred, normal_raw, sem, **kwargs):
+    """The same rounds with the loop head on the DEVICE (ngp_test_round_begin): N_alive, N_samples of the round, the
+    running `samples` sum and the total sample count live in a device record, the alive list is compacted by a kernel
+    (ngp_alive_compact, order kept), and the host enqueues round after round without waiting for any of it.  It reads
+    the record back through pinned memory `_ROUND_LAG` rounds late: to stop (the rounds enqueued in between do nothing
+    once the record says done) and to size its launches — a stale N_alive is an upper bound of the current one, the
+    marcher / compositor take the exact sizes from the device, and the field evaluates the (few) padding rows beyond
+    N_alive * N_samples on zero inputs whose results nobody reads.  Per-ray results are bit-identical to the host-driven
+    loop above and to volume_render_reference (same schedule, same samples, row results independent of the batch).
+    Opt-in (see _DEVICE_ROUNDS): the frame is bound by its field kernels, not by the round trips."""
+    N_rays = len(rays_o)
+    device = rays_o.device
+    exp_step_factor = kwargs.get('exp_step_factor', 0.)
+    classes = kwargs.get('num_classes', 7)
+    T_threshold = kwargs.get('T_threshold', 1e-4)
+    max_total = int(kwargs.get('max_samples', MAX_SAMPLES))
+    min_samples = 1 if exp_step_factor == 0 else 4
+    f32 = torch.float32
+    state = torch.zeros(8, dtype=torch.int32, device=device)
+    state[0:1].fill_(N_rays)
+    alive = [torch.arange(N_rays, device=device), torch.empty(N_rays, dtype=torch.int64, device=device)]
+    cap = max(N_rays, min_samples * N_rays)
+    xyzs = torch.empty(cap, 3, dtype=f32, device=device)
+    dirs = torch.empty(cap, 3, dtype=f32, device=device)
+    deltas = torch.empty(cap, dtype=f32, device=device)
+    ts = torch.empty(cap, dtype=f32, device=device)
+    n_eff = torch.empty(N_rays, dtype=torch.int32, device=device)
+    counts = torch.empty((N_rays + 1023) // 1024, dtype=torch.int32, device=device)
+    host = [torch.zeros(8, dtype=torch.int32).pin_memory() for _ in range(_ROUND_LAG)]
+    events = [None] * _ROUND_LAG
+    stream = torch.cuda.current_stream()
+    nh = N_rays                     # host's (stale, hence upper) bound of the number of alive rays
+    cur = 0
+    for rnd in range(max_total):    # every round adds at least one sample per ray to the running sum
+        slot = rnd % _ROUND_LAG
+        if events[slot] is not None:
+            events[slot].synchronize()          # the record as it stood _ROUND_LAG rounds ago
+            if int(host[slot][3]) or int(host[slot][5]) == 0:
+                break
+            nh = int(host[slot][5])
+        n_ub = min(64 * nh, max(N_rays, min_samples * nh))   # >= N_alive * N_samples of this round
+        call("test_round_begin", state, N_rays, min_samples, max_total)
+        xyzs[:n_ub].zero_()         # padding rows must hold finite inputs
+        dirs[:n_ub].zero_()
+        call("raymarching_test_rounds", rays_o, rays_d, hits_t, alive[cur], model.density_bitfield, int(model.cascades),
+             float(model.scale), float(exp_step_factor), int(model.grid_size), MAX_SAMPLES, state, nh,
+             xyzs, dirs, deltas, ts, n_eff)
+        sigmas, rgbs, normals_pred, normals_raw, sems = model.forward_test(xyzs[:n_ub], dirs[:n_ub], **kwargs)
+        call("composite_test_fw_rounds", sigmas.contiguous(), rgbs.contiguous(), normals_pred.contiguous(),
+             normals_raw.contiguous(), sems.contiguous(), deltas, ts, alive[cur], float(T_threshold), int(classes), n_eff,
+             state, nh, opacity, depth, rgb, normal_pred, normal_raw, sem)
+        call("alive_compact", alive[cur], state, nh, counts, alive[1 - cur])
+        cur = 1 - cur
+        host[slot].copy_(state, non_blocking=True)
+        events[slot] = torch.cuda.Event()
+        events[slot].record(stream)
+    total_samples = state[6:8].view(torch.int64)[0]
     if kwargs.get('use_skybox', False):
         rgb_bg = model.forward_skybox(rays_d)
         rgb += rgb_bg * (1 - opacity)[:, None]

@@ -1355,13 +1355,21 @@ def test_test_time_render_fast_loop_identical(ngp):
     tr.wait()
     n = 120 * 120
     o, d = scene.rays(torch.full((n,), 3, dtype=torch.long, device=DEV), torch.arange(n, device=DEV))
-    for thr in (1e-2, 1e-4):
-        fast = render(model, o, d, test_time=True, T_threshold=thr)
-        ref = render(model, o, d, test_time=True, T_threshold=thr, reference_test_loop=True)
-        assert int(fast["total_samples"]) == int(ref["total_samples"]) > 0
+    # device_rounds = loop head, alive compaction and sample count on the device, no host round trip per round; default =
+    # the host-driven fast loop (one sync per round); reference_test_loop = the literal loop.
+    # max_samples = 24 ends the loop on the `samples < max_samples` head with rays still alive; exp_step_factor > 0
+    # takes the 4-samples-per-round minimum.
+    for kw in (dict(T_threshold=1e-2), dict(T_threshold=1e-4), dict(T_threshold=1e-4, max_samples=24),
+               dict(T_threshold=1e-3, exp_step_factor=1 / 256)):
+        fast = render(model, o, d, test_time=True, device_rounds=True, **kw)
+        host = render(model, o, d, test_time=True, **kw)
+        ref = render(model, o, d, test_time=True, reference_test_loop=True, **kw)
+        assert int(fast["total_samples"]) == int(ref["total_samples"]) == int(host["total_samples"]) > 0, kw
         for k in ("opacity", "depth", "rgb", "normal_pred", "normal_raw", "semantic", "points"):
-            assert torch.equal(fast[k], ref[k]), k
-        assert float(fast["opacity"].max()) > 0.9
+            assert torch.equal(fast[k], ref[k]), (k, kw)
+            assert torch.equal(host[k], ref[k]), (k, kw)
+        if "max_samples" not in kw:
+            assert float(fast["opacity"].max()) > 0.9
 
 
 def test_render_with_no_samples(ngp):
