@@ -18,11 +18,10 @@
  *     (safe to capture into a hipGraph);
  *   - all floating point is fp32, indices are int32/int64 as the reference's;
  *   - empty batches (n == 0) are valid and return NGP_OK before any pointer is looked at;
- *   - a few NGP_* environment variables, each read ONCE per process, select launch parameters or the
- *     tiled MLP kernels for A/B timing (NGP_ADAM_BLOCKS, NGP_WGRAD_BLOCKS, NGP_MLP_NO_STREAM,
- *     NGP_MLP_NO_STREAM_WGRAD, NGP_ADAM_DENSE_ZERO); results are the same up to summation order.
- *     Superseded kernel variants (NGP_GRID_BWD_SIMPLE / _NOPAIR / _NOSLIDE, NGP_MARCH_LANE_PER_RAY)
- *     exist only in the A/B build (-DNGP_AB_VARIANTS, `NGP_AB_VARIANTS=1 python -m instant-ngp-pp_amd.build`).
+ *   - the product build reads NO environment variable.  Switches for A/B timing (NGP_ADAM_BLOCKS, NGP_WGRAD_BLOCKS,
+ *     NGP_MLP_NO_STREAM, NGP_MLP_NO_STREAM_WGRAD, NGP_MLP_STREAM_HEADS, NGP_ADAM_DENSE_ZERO, NGP_GRID_GATHER_OLD) and the
+ *     superseded kernel variants (NGP_GRID_BWD_SIMPLE / _NOPAIR / _NOSLIDE, NGP_MARCH_LANE_PER_RAY, ...) exist only in the
+ *     A/B build (-DNGP_AB_VARIANTS, `NGP_AB_VARIANTS=1 python -m instant-ngp-pp_amd.build`).
  *
  * Each entry point cites the reference interface it replaces.
  */

@@ -13,6 +13,16 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Tuning switches for A/B timing exist in the A/B build only (-DNGP_AB_VARIANTS); the product build reads no environment
+// variable and keeps no other hidden state.
+#ifdef NGP_AB_VARIANTS
+static inline bool ab_flag(const char* name) { return getenv(name) != nullptr; }
+static inline long ab_long(const char* name, long dflt) { const char* e = getenv(name); const long v = e ? atol(e) : 0; return v > 0 ? v : dflt; }
+#else
+static inline constexpr bool ab_flag(const char*) { return false; }
+static inline constexpr long ab_long(const char*, long dflt) { return dflt; }
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1631,7 +1641,7 @@ void launch_wgrad(GemmArgs p, hipStream_t st)
     const int64_t n = p.K;
     const bool big_m = p.M > 32, big_n = p.N > 32;
     const int64_t tiles = (int64_t)ngp_blocks(p.M, big_m ? 128 : 32) * ngp_blocks(p.N, big_n ? 128 : 32);
-    static const int target_blocks = getenv("NGP_WGRAD_BLOCKS") ? atoi(getenv("NGP_WGRAD_BLOCKS")) : 768; // 3 workgroups per CU x 256 CUs
+    static const int target_blocks = (int)ab_long("NGP_WGRAD_BLOCKS", 768); // 3 workgroups per CU x 256 CUs
     int64_t splits = target_blocks / (tiles > 0 ? tiles : 1);
     if (splits < 1) splits = 1;
     int64_t chunk = (n + splits - 1) / splits;
@@ -1661,6 +1671,7 @@ inline bool xf_args_ok(const float* dz2, int64_t lddz2, const float* W2, int64_t
 }
 
 } // namespace
+
 
 extern "C" {
 
@@ -1707,10 +1718,10 @@ int ngp_mlp2_fwd(const float* x, int64_t ldx, const float* W1, int64_t ldw1, con
     p.vecA = aligned16(x) && (ldx % 4 == 0); p.vecB = aligned16(W1) && (ldw1 % 4 == 0);
     p.f2_W2 = W2; p.f2_ldw2 = ldw2; p.f2_b2 = b2; p.f2_out = out; p.f2_ldo = ldo; p.f2_nout = n_out; p.f2_act = act2;
     dim3 grid(ngp_blocks(n, 128), 1);
-    static const bool stream_ok = !getenv("NGP_MLP_NO_STREAM");
+    static const bool stream_ok = !ab_flag("NGP_MLP_NO_STREAM");
     const bool wide_ok = H == 128 && (n_in == 128 || n_in == 144 || n_in == 160);
     // the 32-wide heads are HBM-bound either way (0.062 ms streaming, 0.060 ms tiled): opt-in only
-    static const bool stream_heads = getenv("NGP_MLP_STREAM_HEADS") != nullptr;
+    static const bool stream_heads = ab_flag("NGP_MLP_STREAM_HEADS");
     const bool head_ok = stream_heads && H == 32 && n_in == 128;
     if (stream_ok && (wide_ok || head_ok) && p.vecA && p.vecB &&
         (act1 == NGP_ACT_RELU || act1 == NGP_ACT_SOFTPLUS) && aligned16(hidden) && ldh % 4 == 0 &&
@@ -1884,7 +1895,7 @@ int ngp_mlp_bwd_input(const float* dz2, int64_t lddz2, const float* W2, int64_t 
     p.M = n; p.N = n_in; p.K = H; p.accumulate = accumulate;
     p.vecA = aligned16(hidden) && (ldh % 4 == 0); p.vecB = aligned16(W1) && (ldw1 % 4 == 0);
     p.xf_dz2 = dz2; p.xf_lddz2 = lddz2; p.xf_W2 = W2; p.xf_ldw2 = ldw2; p.xf_nout = n_out; p.xf_act = act1;
-    static const bool stream_ok = !getenv("NGP_MLP_NO_STREAM");
+    static const bool stream_ok = !ab_flag("NGP_MLP_NO_STREAM");
     if (stream_ok && H == 128 && n_in == 128 && !accumulate && p.vecA && aligned16(dx) && lddx % 4 == 0 &&
         (act1 == NGP_ACT_RELU || act1 == NGP_ACT_SOFTPLUS) && n <= (int64_t)32 * 0x7fffff00) {
         // streaming kernel (chosen by shape only, see ngp_mlp2_fwd); out-of-range xf_nout columns read as zero,
@@ -1949,7 +1960,7 @@ int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t
     static const int wgrad_exp = getenv("NGP_WGRAD_EXP") ? atoi(getenv("NGP_WGRAD_EXP")) : 0;
     p.exp = wgrad_exp;
 #endif
-    static const bool stream_ok = !getenv("NGP_MLP_NO_STREAM") && !getenv("NGP_MLP_NO_STREAM_WGRAD");
+    static const bool stream_ok = !ab_flag("NGP_MLP_NO_STREAM") && !ab_flag("NGP_MLP_NO_STREAM_WGRAD");
     if (stream_ok && H == 128 && (n_in == 128 || n_in == 144 || n_in == 160) && p.vecA && p.vecB &&
         (act1 == NGP_ACT_RELU || act1 == NGP_ACT_SOFTPLUS)) {
         hipStream_t st = (hipStream_t)stream;
@@ -2025,15 +2036,12 @@ int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    static const int64_t cap = [] {
-        const char* e = getenv("NGP_ADAM_BLOCKS");
-        const long c = e ? atol(e) : 0;
-        return (int64_t)(c > 0 ? c : 512);  // 2 workgroups per CU: 5.2 TB/s alone (2048: 4.5) and leaves wave slots to other streams
-    }();
+    // 2 workgroups per CU: 5.2 TB/s alone (2048: 4.5) and leaves wave slots to other streams
+    static const int64_t cap = ab_long("NGP_ADAM_BLOCKS", 512);
     int64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > cap) blocks = cap;
-    static const bool sparse_zero = !getenv("NGP_ADAM_DENSE_ZERO");
+    static const bool sparse_zero = !ab_flag("NGP_ADAM_DENSE_ZERO");
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, step_size, beta1, beta2, eps, bc2_sqrt, weight_decay, grad_scale, zero_grad,
                        sparse_zero);

@@ -308,3 +308,13 @@ def test_product_build_asm_loads_are_covered(ngp, tmp_path):
     with_loads = [l for l in lines if " 0 asm loads" not in l]
     assert any("mlp_stream_fwd_kernel" in l for l in with_loads) and any("mlp_stream_dgrad_kernel" in l for l in with_loads), \
         "the checker found no inline-assembly loads in the streaming kernels: its parsing no longer matches the ISA listing"
+
+
+def test_product_library_reads_no_environment(ngp):
+    """include/ngp_hip.h: "the product build reads NO environment variable" — the shared object must not even import
+    getenv (A/B switches are compiled in with -DNGP_AB_VARIANTS only)."""
+    if os.environ.get("NGP_AB_VARIANTS"):
+        pytest.skip("A/B build")
+    ngp._lib.load()
+    out = subprocess.check_output(["nm", "-D", ngp._lib.LIB_PATH], text=True)
+    assert "getenv" not in out
