@@ -966,9 +966,9 @@ int ngp_composite_test_fw_rounds(const float* sigmas, const float* rgbs, const f
                                  int n_alive_bound, float* opacity, float* depth, float* rgb, float* normal,
                                  float* normal_raw, float* sem, void* stream)
 {
-    if (n_alive_bound < 0 || classes < 0 || !state) return NGP_EINVAL;
+    if (n_alive_bound < 0 || classes < 0) return NGP_EINVAL;
     if (n_alive_bound == 0) return NGP_OK;
-    if (!sigmas || !rgbs || !normals || !normals_raw || !deltas || !ts || !alive_indices || !n_eff_samples ||
+    if (!state || !sigmas || !rgbs || !normals || !normals_raw || !deltas || !ts || !alive_indices || !n_eff_samples ||
         !opacity || !depth || !rgb || !normal || !normal_raw || (classes && (!sem || !sems))) return NGP_EINVAL;
     hipLaunchKernelGGL(composite_test_fw_kernel, dim3(ngp_blocks(n_alive_bound, 64)), dim3(64), 0, (hipStream_t)stream,
                        sigmas, rgbs, normals, normals_raw, sems, deltas, ts, alive_indices, T_threshold, classes,
@@ -1047,7 +1047,8 @@ int ngp_render_loss_fused(const float* sigmas, const float* rgbs, const float* d
                           float* depth, float* rgb, float* normal_pred, float* sem, float* ws, float* loss_o,
                           float* loss_p, float* terms, float* dL_dsigmas, float* dL_drgbs, void* stream)
 {
-    if (n_rays < 1 || classes < 0 || classes > 8 || ld_normal < 3 || ld_sem < classes) return NGP_EINVAL;
+    if (n_rays < 0 || classes < 0 || classes > 8 || ld_normal < 3 || ld_sem < classes) return NGP_EINVAL;
+    if (n_rays == 0) return NGP_OK;
     if (!rays_a || !target_rgb || !total_samples || !vr_samples || !opacity || !depth || !rgb || !normal_pred ||
         (classes && !sem) || !loss_o || !loss_p || !terms) return NGP_EINVAL;
     hipStream_t st = (hipStream_t)stream;

@@ -1074,9 +1074,9 @@ int ngp_raymarching_test_rounds(const float* rays_o, const float* rays_d, float*
                                 int grid_size, int max_samples, int32_t* state, int n_alive_bound, float* xyzs,
                                 float* dirs, float* deltas, float* ts, int32_t* n_eff_samples, void* stream)
 {
-    if (n_alive_bound < 0 || cascades < 1 || grid_size < 1 || grid_size > 1024 || !state) return NGP_EINVAL;
+    if (n_alive_bound < 0 || cascades < 1 || grid_size < 1 || grid_size > 1024) return NGP_EINVAL;
     if (n_alive_bound == 0) return NGP_OK;
-    if (!rays_o || !rays_d || !hits_t || !alive_indices || !density_bitfield || !xyzs || !dirs || !deltas || !ts ||
+    if (!state || !rays_o || !rays_d || !hits_t || !alive_indices || !density_bitfield || !xyzs || !dirs || !deltas || !ts ||
         !n_eff_samples) return NGP_EINVAL;
     hipLaunchKernelGGL(march_test_kernel, dim3(ngp_blocks(n_alive_bound, 64)), dim3(64), 0, (hipStream_t)stream,
                        rays_o, rays_d, hits_t, alive_indices, density_bitfield, cascades, scale, exp_step_factor,
@@ -1087,9 +1087,9 @@ int ngp_raymarching_test_rounds(const float* rays_o, const float* rays_d, float*
 int ngp_alive_compact(const int64_t* alive_in, int32_t* state, int n_alive_bound, int32_t* block_counts,
                       int64_t* alive_out, void* stream)
 {
-    if (n_alive_bound < 0 || !state) return NGP_EINVAL;
+    if (n_alive_bound < 0) return NGP_EINVAL;
     if (n_alive_bound == 0) return NGP_OK;
-    if (!alive_in || !block_counts || !alive_out) return NGP_EINVAL;
+    if (!state || !alive_in || !block_counts || !alive_out) return NGP_EINVAL;
     const int blocks = (int)ngp_blocks(n_alive_bound, 1024);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(alive_count_kernel, dim3(blocks), dim3(1024), 0, st, alive_in, state, block_counts);

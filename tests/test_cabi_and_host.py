@@ -217,11 +217,11 @@ def test_empty_and_negative_batches_through_the_c_abi(ngp):
     size_args = {"n", "n_rays", "n_alive", "count", "n_seg", "n_bytes"}
     desc = _lib.GridDesc()
     assert _lib.call_host("grid_layout", 16, 8, 19, 16, 1.3195079, desc) > 0
-    small = {"degree": 4, "max_hits": 1, "n_voxels": 1, "n_spheres": 1, "cascades": 1, "n_samples": 1, "classes": 1, "width": 1,
+    small = {"min_samples": 1, "max_samples_total": 1024, "degree": 4, "max_hits": 1, "n_voxels": 1, "n_spheres": 1, "cascades": 1, "n_samples": 1, "classes": 1, "width": 1,
              "cols": 1, "grid_size": 128, "max_samples": 1024, "n_in": 16, "n_out": 1, "H": 32, "step": 1}
     # entry points whose empty call needs more than NULLs (an output scalar, a counter) are exercised on the GPU instead
     needs_outputs = {"ngp_density_grid_ema_threshold", "ngp_raymarching_train", "ngp_nerf_loss", "ngp_sumsq", "ngp_sumsq_if",
-                     "ngp_row_norm_sum", "ngp_live_rows"}
+                     "ngp_row_norm_sum", "ngp_live_rows", "ngp_test_round_begin"}   # (n_rays there is the frame's ray count)
     checked = 0
     for name, (_, args) in _lib.PROTOS.items():
         names = [a for _, a in args]
