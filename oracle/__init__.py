@@ -328,6 +328,29 @@ def linear_fwd(x, W, b, act):
     return y
 
 
+def field_forward(field, x, d):
+    """the whole NGP field of `field` (an oracle.field.CpuNGP without appearance codes) on points x (N,3) and
+    directions d (N,3) in ONE C call, OpenMP over the points -> (sigmas, rgbs, normals_raw, normals_pred, sems)"""
+    x, d = _f(x), _f(d)
+    n = len(x)
+    C7 = int(field.classes)
+    sig = np.zeros(n, np.float32)
+    rgb = np.zeros((n, 3), np.float32)
+    nr = np.zeros((n, 3), np.float32)
+    npd = np.zeros((n, 3), np.float32)
+    sem = np.zeros((n, C7), np.float32)
+    w = [_f(a) for a in (field.W1, field.b1, field.W2, field.b2, field.Wr1, field.Wr2, field.Wn1, field.Wn2, field.Ws1,
+                         field.Ws2)]
+    rc = lib().ngp_cpu_field_forward(C.byref(field.xyz_desc), _p(_f(field.xyz_table)), C.byref(field.rgb_desc),
+                                     _p(_f(field.rgb_table)), _p(w[0]), _p(w[1]), _p(w[2]), _p(w[3]), _p(w[4]),
+                                     int(field.Wr1.shape[1]), _p(w[5]), _p(w[6]), _p(w[7]), _p(w[8]), _p(w[9]),
+                                     f32(field.scale), C7, _p(x), _p(d), C.c_int64(n), _p(sig), _p(rgb), _p(nr), _p(npd),
+                                     _p(sem))
+    if rc != 0:
+        raise RuntimeError(f"ngp_cpu_field_forward failed: {rc}")
+    return sig, rgb, nr, npd, sem
+
+
 def num_threads():
     return int(lib().ngp_cpu_num_threads())
 

@@ -784,6 +784,167 @@ int ngp_cpu_linear_fwd(const float* x, int64_t ldx, const float* W, const float*
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * The whole NGP field for a batch of points in ONE call, OpenMP over the points (bench.py's cpu_baseline leg: the numpy
+ * glue of oracle/field.py between the per-layer calls above runs under the interpreter lock and does not scale over
+ * cores).  Same arithmetic as oracle/field.py::CpuNGP.__call__ — models/networks.py:165-240: normalised position, density
+ * encoder + head with Softplus, d(sigma)/dx by back-substitution, colour encoder, SH(4) of (normalize(d)+1)/2, rgb_net
+ * (input padded with ones to n_rgb_in), the two 32-wide heads, -normalize, softmax — checked against it in
+ * tests/test_oracle_kat.py.  No appearance codes (n_rgb_in - 144 columns are the ones-padding).
+ * ---------------------------------------------------------------------------------------- */
+static void grid_fwd_one(const grid_desc* d, const float* table, const float* x3, float* out /* L*F */)
+{
+    const int L = (int)d->n_levels, F = (int)d->n_features;
+    for (int l = 0; l < L; l++) {
+        float w[3]; uint32_t g[3];
+        for (int k = 0; k < 3; k++) {
+            const float p = fmaf(d->scale[l], x3[k], 0.5f);
+            const float fl = floorf(p);
+            g[k] = (uint32_t)(int)fl; w[k] = p - fl;
+        }
+        float* o = out + (size_t)l * F;
+        for (int f = 0; f < F; f++) o[f] = 0;
+        for (int c = 0; c < 8; c++) {
+            float wt = 1; uint32_t q[3];
+            for (int k = 0; k < 3; k++) {
+                if (c & (1 << k)) { wt *= w[k]; q[k] = g[k] + 1; } else { wt *= 1 - w[k]; q[k] = g[k]; }
+            }
+            const float* row = table + (size_t)grid_row(d, l, q[0], q[1], q[2]) * F;
+            for (int f = 0; f < F; f++) o[f] = fmaf(wt, row[f], o[f]);
+        }
+    }
+}
+
+static void grid_bwd_input_one(const grid_desc* d, const float* table, const float* x3, const float* go_all, float* acc)
+{
+    const int L = (int)d->n_levels, F = (int)d->n_features;
+    acc[0] = acc[1] = acc[2] = 0;
+    for (int l = 0; l < L; l++) {
+        float w[3]; uint32_t g[3];
+        for (int k = 0; k < 3; k++) {
+            const float p = fmaf(d->scale[l], x3[k], 0.5f);
+            const float fl = floorf(p);
+            g[k] = (uint32_t)(int)fl; w[k] = p - fl;
+        }
+        const float* go = go_all + (size_t)l * F;
+        for (int gd = 0; gd < 3; gd++) {
+            const int a = (gd + 1) % 3, b = (gd + 2) % 3;
+            for (int c = 0; c < 4; c++) {
+                uint32_t q0[3], q1[3]; float wt = d->scale[l];
+                const int ca = c & 1, cb = (c >> 1) & 1;
+                wt *= ca ? w[a] : 1 - w[a];
+                wt *= cb ? w[b] : 1 - w[b];
+                q0[a] = q1[a] = g[a] + (uint32_t)ca; q0[b] = q1[b] = g[b] + (uint32_t)cb;
+                q0[gd] = g[gd]; q1[gd] = g[gd] + 1;
+                const float* r0 = table + (size_t)grid_row(d, l, q0[0], q0[1], q0[2]) * F;
+                const float* r1 = table + (size_t)grid_row(d, l, q1[0], q1[1], q1[2]) * F;
+                float dot = 0;
+                for (int f = 0; f < F; f++) dot += go[f] * (r1[f] - r0[f]);
+                acc[gd] += wt * dot;
+            }
+        }
+    }
+}
+
+static inline void neg_normalize3(const float* v, float* o)
+{
+    const float n = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-6f);
+    o[0] = -v[0] / n; o[1] = -v[1] / n; o[2] = -v[2] / n;
+}
+
+int ngp_cpu_field_forward(const grid_desc* xd, const float* xyz_table, const grid_desc* rd, const float* rgb_table,
+                          const float* W1, const float* b1, const float* W2, const float* b2,   /* 128x128, 128, 1x128, 1 */
+                          const float* Wr1, int n_rgb_in, const float* Wr2,                     /* 128 x n_rgb_in, 16 x 128 */
+                          const float* Wn1, const float* Wn2, const float* Ws1, const float* Ws2, /* 32x128, 16x32 each */
+                          float scale, int classes, const float* x, const float* dirs, int64_t n,
+                          float* sigma, float* rgb, float* normals_raw, float* normals_pred, float* sems)
+{
+    if ((int)xd->n_levels * (int)xd->n_features != 128 || (int)rd->n_levels * (int)rd->n_features != 128) return -22;
+    if (n_rgb_in < 144 || n_rgb_in > 176 || classes < 0 || classes > 16) return -22;
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < n; i++) {
+        float xn[3], feat[128], z1[128], a1[128], dz1[128], dfeat[128], featc[128], inp[176], hid[128], h32[32];
+        for (int k = 0; k < 3; k++) xn[k] = (x[3 * i + k] + scale) / (2 * scale);
+        grid_fwd_one(xd, xyz_table, xn, feat);
+        float h = b2[0];
+        for (int o = 0; o < 128; o++) {
+            float a = b1[o];
+            const float* wr = W1 + (size_t)o * 128;
+            for (int k = 0; k < 128; k++) a += feat[k] * wr[k];
+            z1[o] = a;
+            a1[o] = act_apply(a, 3);
+            h += W2[o] * a1[o];
+        }
+        sigma[i] = act_apply(h, 3);
+        /* d sigma / d x: dh = sigmoid(h) (derivative of Softplus), back through the head, then the grid input gradient */
+        const float dh = 1.0f / (1.0f + expf(-h));
+        for (int o = 0; o < 128; o++) dz1[o] = dh * W2[o] * (1.0f / (1.0f + expf(-z1[o])));
+        for (int k = 0; k < 128; k++) dfeat[k] = 0;
+        for (int o = 0; o < 128; o++) {
+            const float* wr = W1 + (size_t)o * 128;
+            for (int k = 0; k < 128; k++) dfeat[k] += dz1[o] * wr[k];
+        }
+        float gr[3];
+        grid_bwd_input_one(xd, xyz_table, xn, dfeat, gr);
+        for (int k = 0; k < 3; k++) gr[k] /= 2 * scale;
+        neg_normalize3(gr, normals_raw + 3 * i);
+        /* colour branch */
+        grid_fwd_one(rd, rgb_table, xn, featc);
+        float dn[3];
+        {
+            const float* d3 = dirs + 3 * i;
+            const float nn = fmaxf(sqrtf(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]), 1e-6f);
+            for (int k = 0; k < 3; k++) dn[k] = d3[k] / nn;
+        }
+        sh_eval((dn[0] + 1) / 2 * 2 - 1, (dn[1] + 1) / 2 * 2 - 1, (dn[2] + 1) / 2 * 2 - 1, 4, inp);
+        for (int k = 0; k < 128; k++) inp[16 + k] = featc[k];
+        for (int k = 144; k < n_rgb_in; k++) inp[k] = 1.0f;
+        for (int o = 0; o < 128; o++) {
+            float a = 0;
+            const float* wr = Wr1 + (size_t)o * n_rgb_in;
+            for (int k = 0; k < n_rgb_in; k++) a += inp[k] * wr[k];
+            hid[o] = a > 0 ? a : 0;
+        }
+        for (int o = 0; o < 3; o++) {
+            float a = 0;
+            const float* wr = Wr2 + (size_t)o * 128;
+            for (int k = 0; k < 128; k++) a += hid[k] * wr[k];
+            rgb[3 * i + o] = 1.0f / (1.0f + expf(-a));
+        }
+        /* normal head, semantic head */
+        for (int o = 0; o < 32; o++) {
+            float a = 0;
+            const float* wr = Wn1 + (size_t)o * 128;
+            for (int k = 0; k < 128; k++) a += featc[k] * wr[k];
+            h32[o] = a > 0 ? a : 0;
+        }
+        float np3[3];
+        for (int o = 0; o < 3; o++) {
+            float a = 0;
+            const float* wr = Wn2 + (size_t)o * 32;
+            for (int k = 0; k < 32; k++) a += h32[k] * wr[k];
+            np3[o] = a;
+        }
+        neg_normalize3(np3, normals_pred + 3 * i);
+        for (int o = 0; o < 32; o++) {
+            float a = 0;
+            const float* wr = Ws1 + (size_t)o * 128;
+            for (int k = 0; k < 128; k++) a += featc[k] * wr[k];
+            h32[o] = a > 0 ? a : 0;
+        }
+        float lg[16], mx = -INFINITY, den = 0;
+        for (int o = 0; o < classes; o++) {
+            float a = 0;
+            const float* wr = Ws2 + (size_t)o * 32;
+            for (int k = 0; k < 32; k++) a += h32[k] * wr[k];
+            lg[o] = a; mx = fmaxf(mx, a);
+        }
+        for (int o = 0; o < classes; o++) { lg[o] = expf(lg[o] - mx); den += lg[o]; }
+        for (int o = 0; o < classes; o++) sems[(size_t)i * classes + o] = lg[o] / den;
+    }
+    return 0;
+}
+
 /* bench.py times the CPU baseline at 1 thread and at all threads */
 void ngp_cpu_set_num_threads(int n)
 {

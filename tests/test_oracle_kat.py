@@ -323,3 +323,34 @@ def test_linear_layer_matches_numpy():
     close(oracle.linear_fwd(x, W, b, "Sigmoid"), 1 / (1 + np.exp(-z)), 1e-5, 1e-5)
     close(oracle.linear_fwd(x, W, b, "Softplus"), np.log1p(np.exp(z)), 1e-5, 1e-5)
     close(oracle.linear_fwd(x, W, None, "Exponential"), np.exp(z - b), 1e-5, 1e-5)
+
+
+def test_fused_cpu_field_matches_layered_field():
+    """oracle.field_forward (the whole field for a batch of points in one C call, OpenMP over the points: what bench.py's
+    cpu_baseline times) against oracle/field.py::CpuNGP (pinned to the reference's NGP by fixture G6)."""
+    from oracle.field import CpuNGP
+    L, F = 16, 8
+    b = float(np.exp(np.log(2048 * 0.5 / 16) / 15))
+    _, nx = oracle.grid_layout(L, F, 19, 16, b)
+    _, nr = oracle.grid_layout(L, F, 21, 16, b)
+    g = np.random.default_rng(5)
+    st = {"xyz_encoder.params": g.uniform(-0.1, 0.1, nx).astype(np.float32),
+          "rgb_encoder.params": g.uniform(-0.1, 0.1, nr).astype(np.float32),
+          "xyz_net.0.weight": (g.normal(size=(128, 128)) * 0.1).astype(np.float32),
+          "xyz_net.0.bias": (g.normal(size=128) * 0.1).astype(np.float32),
+          "xyz_net.2.weight": (g.normal(size=(1, 128)) * 0.1).astype(np.float32),
+          "xyz_net.2.bias": np.full(1, 0.3, np.float32),
+          "rgb_net.params": (g.normal(size=128 * 144 + 16 * 128) * 0.1).astype(np.float32),
+          "norm_pred_header.params": (g.normal(size=32 * 128 + 16 * 32) * 0.1).astype(np.float32),
+          "semantic_header.params": (g.normal(size=32 * 128 + 16 * 32) * 0.1).astype(np.float32)}
+    f = CpuNGP(st, scale=0.5)
+    n = 700
+    x = (g.random((n, 3)) - 0.5).astype(np.float32)
+    x[0] = [-0.5, -0.5, -0.5]
+    x[1] = [0.5, 0.5, 0.5]
+    d = g.normal(size=(n, 3)).astype(np.float32)
+    ref = f(x, d)
+    got = oracle.field_forward(f, x, d)
+    for a, c, name in zip(ref[:5], got, ("sigmas", "rgbs", "normals_raw", "normals_pred", "sems")):
+        assert a.shape == c.shape, name
+        np.testing.assert_allclose(c, a, rtol=2e-5, atol=2e-6, err_msg=name)
