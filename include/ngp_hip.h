@@ -415,6 +415,12 @@ int ngp_mlp2_fwd(const float* x, int64_t ldx, const float* W1, int64_t ldw1, con
                  const float* W2, int64_t ldw2, const float* b2, int act2, int64_t n, int n_in, int H,
                  int n_out, float* hidden, int64_t ldh, float* out, int64_t ldo, void* stream);
 
+/* the same, also writing dact_out (n, n_out, row stride ldo) = act2'(z2) expressed through the output — bitwise what
+ * ngp_act_bwd(NULL, out, ...) would compute afterwards (the density head's d sigma / d x pass starts from it) */
+int ngp_mlp2_fwd_dact(const float* x, int64_t ldx, const float* W1, int64_t ldw1, const float* b1, int act1,
+                      const float* W2, int64_t ldw2, const float* b2, int act2, int64_t n, int n_in, int H,
+                      int n_out, float* hidden, int64_t ldh, float* out, int64_t ldo, float* dact_out, void* stream);
+
 int ngp_linear_bwd_input(const float* dz, int64_t lddz, const float* W, int64_t ldw,
                          int64_t n, int n_in, int n_out, float* dx, int64_t lddx,
                          int accumulate /* dx += instead of dx = */, void* stream);

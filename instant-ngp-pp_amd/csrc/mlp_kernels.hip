@@ -47,6 +47,7 @@ struct GemmArgs {
     // F2 kernels (FWD of a 2-layer MLP whose hidden width fits one column tile): the 1..4-wide second
     // layer out = act2(hidden . W2^T + b2) is applied to the activated tile in the epilogue
     const float* f2_W2; int64_t f2_ldw2; const float* f2_b2; float* f2_out; int64_t f2_ldo; int f2_nout, f2_act;
+    float* f2_dact;   // optional (n, n_out): act2'(z2) expressed through the output (what ngp_act_bwd gives for a unit gradient)
     const float* xf_dz2; int64_t xf_lddz2;
     const float* xf_W2; int64_t xf_ldw2;
     int xf_nout, xf_act;
@@ -73,6 +74,18 @@ __device__ __forceinline__ float act_fwd(float v, int act)
         case NGP_ACT_SOFTPLUS: return softplus_fast(v);
         case NGP_ACT_EXP: return __expf(v);
         default: return v;
+    }
+}
+
+// derivative of an activation expressed through its OUTPUT y, for a unit upstream gradient (bitwise what act_bwd_kernel writes)
+__device__ __forceinline__ float act_dout(float y, int act)
+{
+    switch (act) {
+        case NGP_ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
+        case NGP_ACT_SIGMOID: return y * (1.0f - y);
+        case NGP_ACT_SOFTPLUS: return -expm1f(-y);
+        case NGP_ACT_EXP: return y;
+        default: return 1.0f;
     }
 }
 
@@ -490,7 +503,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p)
                 float sum = p.f2_b2 ? p.f2_b2[o] : 0.0f;
 #pragma unroll
                 for (int w = 0; w < WN; w++) sum += red[(w * BM + row) * F2 + o];
-                p.f2_out[m * p.f2_ldo + o] = act_fwd(sum, p.f2_act);
+                const float yv = act_fwd(sum, p.f2_act);
+                p.f2_out[m * p.f2_ldo + o] = yv;
+                if (p.f2_dact) p.f2_dact[m * p.f2_ldo + o] = act_dout(yv, p.f2_act);
             }
         }
         return;
@@ -726,8 +741,11 @@ __global__ void __launch_bounds__(512) mlp_stream_fwd_kernel(GemmArgs p, int n_t
                 const int rr = ((li >> 4) & 1) * 8 + ((li >> 3) & 1) * 4 + ((li >> 2) & 1) * 2 + ((li >> 1) & 1);
                 const int64_t m = m0 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
                 const int oo = og * OGW + o;
-                if ((li & 1) == 0 && oo < nout && m < p.M)
-                    p.f2_out[m * p.f2_ldo + oo] = act_fwd(tot + b2s[oo], f2_act);
+                if ((li & 1) == 0 && oo < nout && m < p.M) {
+                    const float yv = act_fwd(tot + b2s[oo], f2_act);
+                    p.f2_out[m * p.f2_ldo + oo] = yv;
+                    if (p.f2_dact) p.f2_dact[m * p.f2_ldo + oo] = act_dout(yv, f2_act);
+                }
             }
         }
     }
@@ -1702,9 +1720,30 @@ int ngp_linear_fwd(const float* x, int64_t ldx, const float* W, int64_t ldw, con
     return ngp_check_launch();
 }
 
+static int mlp2_fwd_impl(const float* x, int64_t ldx, const float* W1, int64_t ldw1, const float* b1, int act1,
+                         const float* W2, int64_t ldw2, const float* b2, int act2, int64_t n, int n_in, int H, int n_out,
+                         float* hidden, int64_t ldh, float* out, int64_t ldo, float* dact, void* stream);
+
 int ngp_mlp2_fwd(const float* x, int64_t ldx, const float* W1, int64_t ldw1, const float* b1, int act1,
                  const float* W2, int64_t ldw2, const float* b2, int act2, int64_t n, int n_in, int H, int n_out,
                  float* hidden, int64_t ldh, float* out, int64_t ldo, void* stream)
+{
+    return mlp2_fwd_impl(x, ldx, W1, ldw1, b1, act1, W2, ldw2, b2, act2, n, n_in, H, n_out, hidden, ldh, out, ldo, nullptr,
+                         stream);
+}
+
+int ngp_mlp2_fwd_dact(const float* x, int64_t ldx, const float* W1, int64_t ldw1, const float* b1, int act1,
+                      const float* W2, int64_t ldw2, const float* b2, int act2, int64_t n, int n_in, int H, int n_out,
+                      float* hidden, int64_t ldh, float* out, int64_t ldo, float* dact_out, void* stream)
+{
+    if (n > 0 && !dact_out) return NGP_EINVAL;
+    return mlp2_fwd_impl(x, ldx, W1, ldw1, b1, act1, W2, ldw2, b2, act2, n, n_in, H, n_out, hidden, ldh, out, ldo, dact_out,
+                         stream);
+}
+
+static int mlp2_fwd_impl(const float* x, int64_t ldx, const float* W1, int64_t ldw1, const float* b1, int act1,
+                         const float* W2, int64_t ldw2, const float* b2, int act2, int64_t n, int n_in, int H, int n_out,
+                         float* hidden, int64_t ldh, float* out, int64_t ldo, float* dact, void* stream)
 {
     if (n < 0 || n_in < 1 || H < 1 || H > 128 || n_out < 1 || n_out > 8 || ldx < n_in || ldw1 < n_in || ldh < H ||
         ldw2 < H || ldo < n_out)
@@ -1717,6 +1756,7 @@ int ngp_mlp2_fwd(const float* x, int64_t ldx, const float* W1, int64_t ldw1, con
     p.M = n; p.N = H; p.K = n_in; p.bias = b1; p.act = act1;
     p.vecA = aligned16(x) && (ldx % 4 == 0); p.vecB = aligned16(W1) && (ldw1 % 4 == 0);
     p.f2_W2 = W2; p.f2_ldw2 = ldw2; p.f2_b2 = b2; p.f2_out = out; p.f2_ldo = ldo; p.f2_nout = n_out; p.f2_act = act2;
+    p.f2_dact = dact;
     dim3 grid(ngp_blocks(n, 128), 1);
     static const bool stream_ok = !ab_flag("NGP_MLP_NO_STREAM");
     const bool wide_ok = H == 128 && (n_in == 128 || n_in == 144 || n_in == 160);

@@ -374,7 +374,12 @@ class _FieldFn(Function):
 
         # density head
         call("grid_fwd", xe.desc, xyz_table, xn, n, feat, 128)
-        if _FUSED_FWD:   # both layers in one launch: the 1-wide second layer rides in the MFMA epilogue
+        if _FUSED_FWD and _FUSED_BWD:
+            # both layers in one launch, the 1-wide second layer in the MFMA epilogue, which also leaves
+            # dz2 = softplus'(z2) = 1 - exp(-sigma): the start of the d(sigma)/dx pass below (no act_bwd launch)
+            call("mlp2_fwd_dact", feat, 128, W1, 128, b1, _SOFTPLUS, W2, 128, b2, _SOFTPLUS, n, 128, 128, 1, a1, 128, sig, 1,
+                 dz2)
+        elif _FUSED_FWD:
             call("mlp2_fwd", feat, 128, W1, 128, b1, _SOFTPLUS, W2, 128, b2, _SOFTPLUS, n, 128, 128, 1, a1, 128, sig, 1)
         else:
             call("linear_fwd", feat, 128, W1, 128, b1, n, 128, 128, _SOFTPLUS, a1, 128, None)
@@ -398,7 +403,8 @@ class _FieldFn(Function):
             live_ev.record(main)
         # analytic d(sigma)/dx: back-substitute ones through the head, then the grid input gradient
         if _FUSED_BWD:
-            call("act_bwd", None, sig, n, _SOFTPLUS, dz2)          # upstream gradient = ones
+            if not _FUSED_FWD:
+                call("act_bwd", None, sig, n, _SOFTPLUS, dz2)      # upstream gradient = ones
             call("mlp_bwd_input", dz2, 1, W2, 128, a1, 128, _SOFTPLUS, W1, 128, n, 128, 128, 1, dfeat, 128, 0)
         else:
             call("mlp_hidden_bwd", None, 0, sig, 1, _SOFTPLUS, W2, 128, a1, 128, _SOFTPLUS, n, 128, 1, None, 0, dz1, 128,

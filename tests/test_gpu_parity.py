@@ -735,6 +735,16 @@ def test_mlp2_fwd_fused(ngp, case):
     close(N(hid_w[:, :H]), h_ref, 2e-5, 2e-5)
     assert not hid_w[:, H:].any()
     close(N(out), o_ref, 3e-5, 3e-5)
+    # ngp_mlp2_fwd_dact: the same launch also leaves act2'(z2) through the output — bitwise ngp_act_bwd(NULL, out)
+    out2 = torch.full((n, n_out), 9.0, device=DEV)
+    hid2 = torch.empty(n, H, device=DEV)
+    dact = torch.full((n, n_out), 9.0, device=DEV)
+    call("mlp2_fwd_dact", T(x), n_in, T(W1), n_in, None if b1 is None else T(b1), act1, T(W2), H,
+         None if b2 is None else T(b2), act2, n, n_in, H, n_out, hid2, H, out2, n_out, dact)
+    assert torch.equal(out2, out) and torch.equal(hid2, hid_w[:, :H].contiguous())
+    want = torch.empty_like(out2)
+    call("act_bwd", None, out2, out2.numel(), act2, want)
+    assert torch.equal(dact, want)
 
 
 @pytest.mark.parametrize("n", [1, 3, 4, 1023, 100003, 4_000_001])
