@@ -497,6 +497,68 @@ __global__ void __launch_bounds__(256) nerf_loss_kernel(const float* __restrict_
     }
 }
 
+// ---- W-lane groups (W = 32: a half-wave, W = 64: a whole wave per ray) for the fused kernel below ------------------
+template <int W> __device__ __forceinline__ float grp_sum(float v)
+{
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, W);
+    return v;
+}
+template <int W> __device__ __forceinline__ float grp_scan_add(float v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < W; o <<= 1) {
+        const float u = __shfl_up(v, o, W);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+template <int W> __device__ __forceinline__ float grp_scan_mul(float v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < W; o <<= 1) {
+        const float u = __shfl_up(v, o, W);
+        if (lane >= o) v *= u;
+    }
+    return v;
+}
+template <int W> __device__ __forceinline__ int grp_first(unsigned long long ballot, int lane64)
+{
+    if (W == 64) return ballot ? (int)__builtin_ctzll(ballot) : -1;
+    const unsigned m = (unsigned)(ballot >> (lane64 & 32));
+    return m ? (__ffs((int)m) - 1) : -1;
+}
+template <int W> __device__ __forceinline__ bool seg_load_w(const int64_t* __restrict__ rays_a, int n_rays, Seg& s, int& lane)
+{
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = gtid / W;
+    lane = threadIdx.x & (W - 1);
+    if (row >= n_rays) return false;
+    s.ray = rays_a[3 * (size_t)row];
+    s.start = rays_a[3 * (size_t)row + 1];
+    s.n = (int)rays_a[3 * (size_t)row + 2];
+    return true;
+}
+template <int W> __device__ __forceinline__ Chunk chunk_alpha_w(const float* __restrict__ sigmas, const float* __restrict__ deltas,
+                                                                int64_t s, bool valid, float T_run, float T_thr, int lane)
+{
+    Chunk c;
+    c.valid = valid;
+    const float sig = valid ? sigmas[s] : 0.0f;
+    const float dl = valid ? deltas[s] : 0.0f;
+    c.a = valid ? 1.0f - __expf(-sig * dl) : 0.0f;
+    const float om = 1.0f - c.a;
+    const float pin = grp_scan_mul<W>(om, lane);
+    float pex = __shfl_up(pin, 1, W);
+    if (lane == 0) pex = 1.0f;
+    c.T_before = T_run * pex;
+    c.T_after = T_run * pin;
+    const bool stopped = valid && (c.T_after <= T_thr);
+    c.first = grp_first<W>(__ballot(stopped), threadIdx.x & 63);
+    c.active = valid && (c.first < 0 || lane <= c.first);
+    return c;
+}
+
 // ------------------------------------------------------------------ fused render + default loss + its gradients
 // Everything between the field's raw outputs and the field's backward on the default recipe (rendering.py:221-249,
 // losses.py:96-105, train.py:307), per ray, in ONE launch (it replaces -normalize x2, softmax, composite_train_fw,
@@ -519,13 +581,14 @@ struct RenderLossArgs {
     float *opacity, *depth, *rgb, *normal, *sem, *ws, *Ro, *Rp, *terms, *d_sigmas, *d_rgbs;
 };
 
-template <int CMAX>
+template <int CMAX, int W>
 __global__ void __launch_bounds__(256) render_loss_fused_kernel(RenderLossArgs p)
 {
-    __shared__ float part[3][8];
-    __shared__ unsigned long long part_n[8];
+    constexpr int RPB = 256 / W;          // rays per block
+    __shared__ float part[3][RPB];
+    __shared__ unsigned long long part_n[RPB];
     Seg sg; int lane;
-    const bool have = seg_load(p.rays_a, p.n_rays, sg, lane);
+    const bool have = seg_load_w<W>(p.rays_a, p.n_rays, sg, lane);
     float s_rgb = 0.0f, s_op = 0.0f, s_dist = 0.0f;
     unsigned long long n_used = 0;
     if (have) {
@@ -540,10 +603,10 @@ __global__ void __launch_bounds__(256) render_loss_fused_kernel(RenderLossArgs p
         float w_run = 0, wt_run = 0, dacc = 0;
         int stop = -1;
         int k0 = 0;
-        for (; k0 < sg.n; k0 += 32) {
+        for (; k0 < sg.n; k0 += W) {
             const int k = k0 + lane;
             const int64_t s = sg.start + k;
-            const Chunk c = chunk_alpha(p.sigmas, p.deltas, s, k < sg.n, T_run, p.T_thr, lane);
+            const Chunk c = chunk_alpha_w<W>(p.sigmas, p.deltas, s, k < sg.n, T_run, p.T_thr, lane);
             const float w = c.active ? c.a * c.T_before : 0.0f;
             float tt = 0.0f, dl = 0.0f;
             if (c.valid) {
@@ -585,16 +648,16 @@ __global__ void __launch_bounds__(256) render_loss_fused_kernel(RenderLossArgs p
             }
             // distortion loss (losses.cu:8-59): inclusive scans of w and w t over the ray
             const float wt = w * tt;
-            const float wi = w_run + half_incl_scan_add(w, lane);
-            const float wti = wt_run + half_incl_scan_add(wt, lane);
-            float we = __shfl_up(wi, 1, 32), wte = __shfl_up(wti, 1, 32);
+            const float wi = w_run + grp_scan_add<W>(w, lane);
+            const float wti = wt_run + grp_scan_add<W>(wt, lane);
+            float we = __shfl_up(wi, 1, W), wte = __shfl_up(wti, 1, W);
             if (lane == 0) { we = w_run; wte = wt_run; }
             if (c.valid) dacc += 2 * (wti * we - wi * wte) + 1.0f / 3 * w * w * dl;
-            w_run = __shfl(wi, 31, 32); wt_run = __shfl(wti, 31, 32);
-            if (c.first >= 0) { stop = k0 + c.first; k0 += 32; break; }
-            T_run = __shfl(c.T_after, 31, 32);
+            w_run = __shfl(wi, W - 1, W); wt_run = __shfl(wti, W - 1, W);
+            if (c.first >= 0) { stop = k0 + c.first; k0 += W; break; }
+            T_run = __shfl(c.T_after, W - 1, W);
         }
-        for (; k0 < sg.n; k0 += 32) {   // behind the stop: zero weight, zero gradients
+        for (; k0 < sg.n; k0 += W) {   // behind the stop: zero weight, zero gradients
             const int k = k0 + lane;
             if (k < sg.n) {
                 const int64_t s = sg.start + k;
@@ -602,13 +665,13 @@ __global__ void __launch_bounds__(256) render_loss_fused_kernel(RenderLossArgs p
                 p.d_rgbs[3 * s] = 0.0f; p.d_rgbs[3 * s + 1] = 0.0f; p.d_rgbs[3 * s + 2] = 0.0f;
             }
         }
-        const int n_live = stop >= 0 ? (stop / 32 + 1) * 32 : sg.n;   // passes B and C stop behind the stop sample's chunk
-        aO = half_sum(aO); aD = half_sum(aD); aR = half_sum(aR); aG = half_sum(aG); aB = half_sum(aB);
-        aNx = half_sum(aNx); aNy = half_sum(aNy); aNz = half_sum(aNz);
-        aRo = half_sum(aRo); aPx = half_sum(aPx); aPy = half_sum(aPy); aPz = half_sum(aPz);
-        dacc = half_sum(dacc);
+        const int n_live = stop >= 0 ? (stop / W + 1) * W : sg.n;   // passes B and C stop behind the stop sample's chunk
+        aO = grp_sum<W>(aO); aD = grp_sum<W>(aD); aR = grp_sum<W>(aR); aG = grp_sum<W>(aG); aB = grp_sum<W>(aB);
+        aNx = grp_sum<W>(aNx); aNy = grp_sum<W>(aNy); aNz = grp_sum<W>(aNz);
+        aRo = grp_sum<W>(aRo); aPx = grp_sum<W>(aPx); aPy = grp_sum<W>(aPy); aPz = grp_sum<W>(aPz);
+        dacc = grp_sum<W>(dacc);
 #pragma unroll
-        for (int cc = 0; cc < CMAX; cc++) aS[cc] = half_sum(aS[cc]);
+        for (int cc = 0; cc < CMAX; cc++) aS[cc] = grp_sum<W>(aS[cc]);
         // ---------------- loss terms and gradient seeds of the ray
         const float e0 = aR - p.gt[3 * r], e1 = aG - p.gt[3 * r + 1], e2 = aB - p.gt[3 * r + 2];
         const float gR = p.g_rgb * 2.0f * e0, gG = p.g_rgb * 2.0f * e1, gB = p.g_rgb * 2.0f * e2;
@@ -633,44 +696,44 @@ __global__ void __launch_bounds__(256) render_loss_fused_kernel(RenderLossArgs p
         float tot = 0.0f;
         if (gd != 0.0f) {
             float wr = 0, wtr = 0;
-            for (int q0 = 0; q0 < n_live; q0 += 32) {
+            for (int q0 = 0; q0 < n_live; q0 += W) {
                 const int k = q0 + lane;
                 const int64_t s = sg.start + k;
                 const bool valid = k < sg.n;
                 const float w = valid ? p.ws[s] : 0.0f, tt = valid ? p.ts[s] : 0.0f, dl = valid ? p.deltas[s] : 0.0f;
-                const float wi = wr + half_incl_scan_add(w, lane);
-                const float wti = wtr + half_incl_scan_add(w * tt, lane);
-                float we = __shfl_up(wi, 1, 32), wte = __shfl_up(wti, 1, 32);
+                const float wi = wr + grp_scan_add<W>(w, lane);
+                const float wti = wtr + grp_scan_add<W>(w * tt, lane);
+                float we = __shfl_up(wi, 1, W), wte = __shfl_up(wti, 1, W);
                 if (lane == 0) { we = wr; wte = wtr; }
                 const float dws = gd * 2 * ((tt * we - wte) + (wt_sum - wti - tt * (w_sum - wi))) + gd * 2.0f / 3 * w * dl;
                 tot += dws * w;
-                wr = __shfl(wi, 31, 32); wtr = __shfl(wti, 31, 32);
+                wr = __shfl(wi, W - 1, W); wtr = __shfl(wti, W - 1, W);
             }
-            tot = half_sum(tot);
+            tot = grp_sum<W>(tot);
         }
         // ---------------- pass C: composite_train_bw
         {
             float T2 = 1.0f, r_run = 0, g_run = 0, b_run = 0, p_run = 0, wr = 0, wtr = 0;
-            for (int q0 = 0; q0 < n_live; q0 += 32) {
+            for (int q0 = 0; q0 < n_live; q0 += W) {
                 const int k = q0 + lane;
                 const int64_t s = sg.start + k;
-                const Chunk c = chunk_alpha(p.sigmas, p.deltas, s, k < sg.n, T2, p.T_thr, lane);
+                const Chunk c = chunk_alpha_w<W>(p.sigmas, p.deltas, s, k < sg.n, T2, p.T_thr, lane);
                 const float w = c.valid ? c.a * c.T_before : 0.0f;
                 float cr = 0, cg = 0, cb = 0, tt = 0, dl = 0, wsv = 0;
                 if (c.valid) {
                     cr = p.rgbs[3 * s]; cg = p.rgbs[3 * s + 1]; cb = p.rgbs[3 * s + 2];
                     tt = p.ts[s]; dl = p.deltas[s]; wsv = p.ws[s];
                 }
-                const float wi = wr + half_incl_scan_add(wsv, lane);
-                const float wti = wtr + half_incl_scan_add(wsv * tt, lane);
-                float we = __shfl_up(wi, 1, 32), wte = __shfl_up(wti, 1, 32);
+                const float wi = wr + grp_scan_add<W>(wsv, lane);
+                const float wti = wtr + grp_scan_add<W>(wsv * tt, lane);
+                float we = __shfl_up(wi, 1, W), wte = __shfl_up(wti, 1, W);
                 if (lane == 0) { we = wr; wte = wtr; }
                 const float dws = gd != 0.0f ? gd * 2 * ((tt * we - wte) + (wt_sum - wti - tt * (w_sum - wi))) + gd * 2.0f / 3 * wsv * dl
                                              : 0.0f;
-                const float ri = r_run + half_incl_scan_add(w * cr, lane);
-                const float gi = g_run + half_incl_scan_add(w * cg, lane);
-                const float bi = b_run + half_incl_scan_add(w * cb, lane);
-                const float pi = p_run + half_incl_scan_add(dws * wsv, lane);
+                const float ri = r_run + grp_scan_add<W>(w * cr, lane);
+                const float gi = g_run + grp_scan_add<W>(w * cg, lane);
+                const float bi = b_run + grp_scan_add<W>(w * cb, lane);
+                const float pi = p_run + grp_scan_add<W>(dws * wsv, lane);
                 if (c.valid) {
                     const float wa = c.active ? w : 0.0f;
                     p.d_rgbs[3 * s] = gR * wa; p.d_rgbs[3 * s + 1] = gG * wa; p.d_rgbs[3 * s + 2] = gB * wa;
@@ -680,20 +743,20 @@ __global__ void __launch_bounds__(256) render_loss_fused_kernel(RenderLossArgs p
                     p.d_sigmas[s] = c.active ? v : 0.0f;
                 }
                 if (c.first >= 0) break;
-                T2 = __shfl(c.T_after, 31, 32);
-                r_run = __shfl(ri, 31, 32); g_run = __shfl(gi, 31, 32); b_run = __shfl(bi, 31, 32); p_run = __shfl(pi, 31, 32);
-                wr = __shfl(wi, 31, 32); wtr = __shfl(wti, 31, 32);
+                T2 = __shfl(c.T_after, W - 1, W);
+                r_run = __shfl(ri, W - 1, W); g_run = __shfl(gi, W - 1, W); b_run = __shfl(bi, W - 1, W); p_run = __shfl(pi, W - 1, W);
+                wr = __shfl(wi, W - 1, W); wtr = __shfl(wti, W - 1, W);
             }
         }
     }
     // ---------------- loss terms of the block's rays: one set of atomics per block
-    const int hw = threadIdx.x >> 5;
-    if ((threadIdx.x & 31) == 0) { part[0][hw] = s_rgb; part[1][hw] = s_op; part[2][hw] = s_dist; part_n[hw] = n_used; }
+    const int hw = threadIdx.x / W;
+    if ((threadIdx.x & (W - 1)) == 0) { part[0][hw] = s_rgb; part[1][hw] = s_op; part[2][hw] = s_dist; part_n[hw] = n_used; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float t0 = 0, t1 = 0, t2 = 0;
         unsigned long long tn = 0;
-        for (int q = 0; q < 8; q++) { t0 += part[0][q]; t1 += part[1][q]; t2 += part[2][q]; tn += part_n[q]; }
+        for (int q = 0; q < RPB; q++) { t0 += part[0][q]; t1 += part[1][q]; t2 += part[2][q]; tn += part_n[q]; }
         t0 *= p.g_rgb; t1 *= p.g_op; t2 *= p.g_dist;
         atomicAdd(p.terms, t0 + t1 + t2);
         atomicAdd(p.terms + 1, t0);
@@ -1066,7 +1129,9 @@ int ngp_render_loss_fused(const float* sigmas, const float* rgbs, const float* d
     a.classes = classes; a.n_rays = n_rays; a.total_samples = total_samples; a.vr_samples = vr_samples;
     a.opacity = opacity; a.depth = depth; a.rgb = rgb; a.normal = normal_pred; a.sem = sem; a.ws = ws;
     a.Ro = loss_o; a.Rp = loss_p; a.terms = terms; a.d_sigmas = dL_dsigmas; a.d_rgbs = dL_drgbs;
-    hipLaunchKernelGGL(render_loss_fused_kernel<8>, seg_grid(n_rays), dim3(256), 0, st, a);
+    // a 32-lane half-wave per ray (W = 64, a whole wave per ray, was measured: 144 us per launch in the step against 85 —
+    // 83 VGPRs leave 5 waves per SIMD, so 8192 wave-sized rays no longer fit the chip at once)
+    hipLaunchKernelGGL((render_loss_fused_kernel<8, 32>), seg_grid(n_rays), dim3(256), 0, st, a);
     return ngp_check_launch();
 }
 
