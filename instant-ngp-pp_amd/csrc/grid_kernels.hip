@@ -196,8 +196,11 @@ __device__ __forceinline__ uint32_t row_offset(const LevelInfo& li, uint32_t x, 
     if (HASHED)
         idx = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & (li.size - 1u);
     else {
-        idx = x + li.res * (y + li.res * z);        // < 2 res^3 <= 2 size: one conditional subtraction is the modulo
-        idx -= idx >= li.size ? li.size : 0u;
+        idx = x + li.res * (y + li.res * z);        // positions in [0, 1]: < 2 res^3 <= 2 size, one subtraction is the modulo
+        if (idx >= li.size) {
+            idx -= li.size;
+            if (idx >= li.size) idx %= li.size;     // a position outside the unit cube (any caller of the C ABI): stay inside the level
+        }
     }
     return (li.offset + idx) * (uint32_t)(F * sizeof(float));
 }

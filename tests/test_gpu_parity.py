@@ -536,6 +536,29 @@ def test_grid_gathers_f8_edge_shapes(ngp, L, n):
     assert bool((gbuf[:guard] == 7.0).all()) and bool((gbuf[-guard:] == 7.0).all())
 
 
+def test_grid_gathers_positions_outside_the_unit_cube(ngp):
+    """The C ABI takes any position: outside [0, 1] the dense levels' index wraps (tcnn: idx % size) instead of leaving
+    the level — the run-leader kernels' one-subtraction modulo falls back to a real one there."""
+    from ngp_amd._lib import call
+    L, Fd, base, pls, log2T = 16, 8, 16, 1.3195079107728942, 15
+    desc, n_params = oracle.grid_layout(L, Fd, log2T, base, pls)
+    g = rng(975)
+    n = 257
+    x = (g.random((n, 3)) * 8.0 - 3.7).astype(np.float32)          # [-3.7, 4.3]
+    x[::5] = g.random((len(x[::5]), 3)).astype(np.float32)         # some inside, so that runs of both kinds meet in a tile
+    table = g.uniform(-1, 1, n_params).astype(np.float32)
+    gd = ngp._lib.GridDesc()
+    assert ngp._lib.call_host("grid_layout", L, Fd, log2T, base, pls, gd) == n_params
+    y = torch.empty(n, L * Fd, device=DEV)
+    call("grid_fwd", gd, T(table), T(x), n, y, L * Fd)
+    close(N(y), oracle.grid_fwd(desc, table, x), 1e-5, 1e-6)
+    dy = g.normal(size=(n, L * Fd)).astype(np.float32)
+    gx = torch.empty(n, 3, device=DEV)
+    call("grid_bwd_input", gd, T(table), T(x), T(dy), L * Fd, n, gx)
+    rgx = oracle.grid_bwd_input(desc, table, x, dy)
+    close(N(gx), rgx, 2e-4, 3e-6 * np.abs(rgx).max())
+
+
 def test_grid_bwd_param_nonfinite_gradient_stays_in_table(ngp):
     """A non-finite upstream gradient must reach only the rows its sample touches: the F = 8 scatter keeps a second
     running sum per corner slot whose line tag is INVALID when both x-corners share a 64-byte line; 0 * inf = NaN in
