@@ -1593,7 +1593,18 @@ __global__ void __launch_bounds__(1024) clip_decide_kernel(const float* __restri
     const int64_t cnt[5] = {n1a, n2a, n1b, n2b, rest ? n_rest : 0};
     for (int k = 0; k < 5; k++) {
         float q = 0.0f;
-        for (int64_t i = threadIdx.x; i < cnt[k]; i += 1024) q = fmaf(ptr[k][i], ptr[k][i], q);
+        // 16-byte pieces, several in flight per thread (one block reads ~80 k floats: the loads' latency is the launch's length)
+        const bool vec = (((uintptr_t)ptr[k]) & 15) == 0;
+        const int64_t n4 = vec ? cnt[k] / 4 : 0;
+        const float4* p4 = reinterpret_cast<const float4*>(ptr[k]);
+        float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+#pragma unroll 4
+        for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+            const float4 v = p4[i];
+            q0 = fmaf(v.x, v.x, q0); q1 = fmaf(v.y, v.y, q1); q2 = fmaf(v.z, v.z, q2); q3 = fmaf(v.w, v.w, q3);
+        }
+        q = (q0 + q1) + (q2 + q3);
+        for (int64_t i = 4 * n4 + threadIdx.x; i < cnt[k]; i += 1024) q = fmaf(ptr[k][i], ptr[k][i], q);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
         if ((threadIdx.x & 63) == 0) ws[k][threadIdx.x >> 6] = q;
