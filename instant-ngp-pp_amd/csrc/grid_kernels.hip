@@ -161,10 +161,11 @@ namespace tile {
 constexpr int F = 8;
 constexpr int LV = 4;                 // levels per wave
 constexpr int S = 32;                 // samples per wave
+
+#ifdef NGP_AB_VARIANTS   // the LDS-staged variant (measured, not shipped: DESIGN.md section 4) lives in the A/B build only
 constexpr int CELL = 68;              // dwords per staged cell: [half 2][corner 8][4] + 4 (bank spread, see phase 3)
 constexpr int LIST = 4 * S;           // dwords per cell list: (gx, gy, gz, -) per run
 constexpr int WAVE_LDS = 2 * LIST + S * CELL;
-
 struct Run {
     float w0, w1, w2;
     uint32_t u;                       // index of the lane's run (= unique cell) among the wave's
@@ -187,6 +188,8 @@ __device__ __forceinline__ Run phase1(const LevelInfo& li, float px, float py, f
     return r;
 }
 
+#endif
+
 // row of a corner for the two kinds of level the tile kernels take (the launcher sends layouts with a hashed level whose
 // size is no power of two, or tables of 4 GiB and more, to the item-per-(sample, level) kernels): byte offset into the table
 template <bool HASHED>
@@ -205,6 +208,7 @@ __device__ __forceinline__ uint32_t row_offset(const LevelInfo& li, uint32_t x, 
     return (li.offset + idx) * (uint32_t)(F * sizeof(float));
 }
 
+#ifdef NGP_AB_VARIANTS
 // phase 2a: the loads of one level (at most 8 per lane: 32 cells x 16 pieces / 64 lanes), into registers
 template <bool HASHED>
 __device__ __forceinline__ void issue_impl(const LevelInfo& li, const char* __restrict__ table, const uint32_t* list,
@@ -247,6 +251,8 @@ __device__ __forceinline__ void commit(float* cells, uint32_t U, int lane, const
     }
 }
 
+#endif
+
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -255,6 +261,7 @@ __device__ __forceinline__ void wave_sync()
 }
 }  // namespace tile
 
+#ifdef NGP_AB_VARIANTS
 __global__ void __launch_bounds__(256, 4) grid_fwd_tile_kernel(GridMeta meta, const float* __restrict__ table,
                                                             const float* __restrict__ x, int64_t n,
                                                             float* __restrict__ y, int64_t ldy)
@@ -436,6 +443,8 @@ __global__ void __launch_bounds__(256, NGP_TILE_BI_WAVES) grid_bwd_input_tile_ke
         }
     }
 }
+
+#endif   // NGP_AB_VARIANTS (staged variant)
 
 // ------------------------------------------------------------------ run-leader gathers (H1, H3; F = 8), no cell staging
 // Same tiles (a wave = 32 consecutive samples x 4 levels, lane = (sample, half row)), but the unique cells are not
@@ -1681,11 +1690,14 @@ int ngp_grid_fwd(const ngp_grid_desc* desc, const float* table, const float* x, 
 #endif
         if (F == 8 && tile_layout_ok(m, desc) && tile_gathers()) {   // the reference's tables: ray-coherent tiles, one load per unique cell corner
             const int64_t waves = ((n + tile::S - 1) / tile::S) * ((m.n_levels + tile::LV - 1) / tile::LV);
-            if (gather_variant() == 2)
+#ifdef NGP_AB_VARIANTS
+            if (gather_variant() == 2) {
                 hipLaunchKernelGGL(grid_fwd_tile_kernel, dim3(ngp_blocks(waves * 64, 256)), dim3(256), 0, st, m, table, x, n,
                                    y, ldy);
-            else
-                hipLaunchKernelGGL(grid_fwd_run_kernel, dim3(ngp_blocks(waves * 64, 256)), dim3(256), 0, st, m, table, x, n,
+                return ngp_check_launch();
+            }
+#endif
+            hipLaunchKernelGGL(grid_fwd_run_kernel, dim3(ngp_blocks(waves * 64, 256)), dim3(256), 0, st, m, table, x, n,
                                    y, ldy);
         } else
             hipLaunchKernelGGL(grid_fwd_kernel<F>, dim3(ngp_blocks(n_items * LPI, 256)), dim3(256), 0, st, m, table, x,
@@ -1806,11 +1818,14 @@ int ngp_grid_bwd_input(const ngp_grid_desc* desc, const float* table, const floa
     const uint32_t wpc = (m.n_levels + tile::LV - 1) / tile::LV;
     if (4 % wpc == 0 && tile_layout_ok(m, desc) && tile_gathers()) {
         const int64_t waves = ((n + tile::S - 1) / tile::S) * wpc;
-        if (gather_variant() == 2)
+#ifdef NGP_AB_VARIANTS
+        if (gather_variant() == 2) {
             hipLaunchKernelGGL(grid_bwd_input_tile_kernel, dim3(ngp_blocks(waves, 4)), dim3(256), 0, st, m, table, x, dL_dy,
                                lddy, n, dL_dx);
-        else
-            hipLaunchKernelGGL(grid_bwd_input_run_kernel, dim3(ngp_blocks(waves, 4)), dim3(256), 0, st, m, table, x, dL_dy,
+            return ngp_check_launch();
+        }
+#endif
+        hipLaunchKernelGGL(grid_bwd_input_run_kernel, dim3(ngp_blocks(waves, 4)), dim3(256), 0, st, m, table, x, dL_dy,
                                lddy, n, dL_dx);
         return ngp_check_launch();
     }
