@@ -284,7 +284,8 @@ int ngp_nerf_loss(const float* rgb, const float* target_rgb, const float* opacit
 int ngp_render_loss_fused(const float* sigmas, const float* rgbs, const float* dsigma_dx, const float* scale3,
                           const float* normal_head, int64_t ld_normal, const float* sem_logits, int64_t ld_sem,
                           const float* dirs, const float* deltas, const float* ts, const int64_t* rays_a,
-                          const float* target_rgb, float T_threshold, int classes, int n_rays, float lambda_opacity,
+                          const float* target_rgb, const float* rgb_bg /* device (3) or NULL: rgb += bg (1 - opacity),
+                          rendering.py:236-241 */, float T_threshold, int classes, int n_rays, float lambda_opacity,
                           float lambda_distortion, int64_t* total_samples, int64_t* vr_samples, float* opacity,
                           float* depth, float* rgb, float* normal_pred, float* sem, float* ws, float* loss_o,
                           float* loss_p, float* terms, float* dL_dsigmas, float* dL_drgbs, void* stream);

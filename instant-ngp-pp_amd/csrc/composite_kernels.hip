@@ -573,6 +573,7 @@ template <int W> __device__ __forceinline__ Chunk chunk_alpha_w(const float* __r
 // Every lane re-reads only what the SAME lane wrote (ws), the scans are recomputed: no cross-lane traffic through memory.
 struct RenderLossArgs {
     const float *sigmas, *rgbs, *dsig_dx, *np_raw, *sem_logits, *dirs, *deltas, *ts, *gt, *scale3;
+    const float* bg;   // optional (3): background colour, rgb += bg (1 - opacity) (rendering.py:236-241)
     const int64_t* rays_a;
     int64_t ld_np, ld_sem;
     float T_thr, g_rgb, g_op, g_dist;
@@ -673,16 +674,24 @@ __global__ void __launch_bounds__(256) render_loss_fused_kernel(RenderLossArgs p
 #pragma unroll
         for (int cc = 0; cc < CMAX; cc++) aS[cc] = grp_sum<W>(aS[cc]);
         // ---------------- loss terms and gradient seeds of the ray
-        const float e0 = aR - p.gt[3 * r], e1 = aG - p.gt[3 * r + 1], e2 = aB - p.gt[3 * r + 2];
+        // the image colour: composited colour over the background (black when bg == NULL)
+        float fR = aR, fG = aG, fB = aB, bg0 = 0.0f, bg1 = 0.0f, bg2 = 0.0f;
+        if (p.bg) {
+            bg0 = p.bg[0]; bg1 = p.bg[1]; bg2 = p.bg[2];
+            const float rest = 1.0f - aO;
+            fR = aR + bg0 * rest; fG = aG + bg1 * rest; fB = aB + bg2 * rest;
+        }
+        const float e0 = fR - p.gt[3 * r], e1 = fG - p.gt[3 * r + 1], e2 = fB - p.gt[3 * r + 2];
         const float gR = p.g_rgb * 2.0f * e0, gG = p.g_rgb * 2.0f * e1, gB = p.g_rgb * 2.0f * e2;
         const float oo = aO + 1e-10f;
         const float lgo = logf(oo);
-        const float gO = p.g_op * (-lgo - 1.0f);
+        // d loss / d opacity: the entropy term, and through the background's weight (1 - opacity)
+        const float gO = p.g_op * (-lgo - 1.0f) - (gR * bg0 + gG * bg1 + gB * bg2);
         const float gd = p.g_dist;
         if (lane == 0) {
             p.total_samples[r] = stop >= 0 ? stop : sg.n;
             p.opacity[r] = aO; p.depth[r] = aD;
-            p.rgb[3 * r] = aR; p.rgb[3 * r + 1] = aG; p.rgb[3 * r + 2] = aB;
+            p.rgb[3 * r] = fR; p.rgb[3 * r + 1] = fG; p.rgb[3 * r + 2] = fB;
             p.normal[3 * r] = aNx; p.normal[3 * r + 1] = aNy; p.normal[3 * r + 2] = aNz;
             p.Ro[r] = aRo; p.Rp[3 * r] = aPx; p.Rp[3 * r + 1] = aPy; p.Rp[3 * r + 2] = aPz;
 #pragma unroll
@@ -1105,7 +1114,7 @@ int ngp_nerf_loss(const float* rgb, const float* target_rgb, const float* opacit
 int ngp_render_loss_fused(const float* sigmas, const float* rgbs, const float* dsigma_dx, const float* scale3,
                           const float* normal_head, int64_t ld_normal, const float* sem_logits, int64_t ld_sem,
                           const float* dirs, const float* deltas, const float* ts, const int64_t* rays_a,
-                          const float* target_rgb, float T_threshold, int classes, int n_rays, float lambda_opacity,
+                          const float* target_rgb, const float* rgb_bg, float T_threshold, int classes, int n_rays, float lambda_opacity,
                           float lambda_distortion, int64_t* total_samples, int64_t* vr_samples, float* opacity,
                           float* depth, float* rgb, float* normal_pred, float* sem, float* ws, float* loss_o,
                           float* loss_p, float* terms, float* dL_dsigmas, float* dL_drgbs, void* stream)
@@ -1123,7 +1132,7 @@ int ngp_render_loss_fused(const float* sigmas, const float* rgbs, const float* d
     }
     RenderLossArgs a;
     a.sigmas = sigmas; a.rgbs = rgbs; a.dsig_dx = dsigma_dx; a.np_raw = normal_head; a.sem_logits = sem_logits;
-    a.dirs = dirs; a.deltas = deltas; a.ts = ts; a.gt = target_rgb; a.scale3 = scale3; a.rays_a = rays_a;
+    a.dirs = dirs; a.deltas = deltas; a.ts = ts; a.gt = target_rgb; a.scale3 = scale3; a.rays_a = rays_a; a.bg = rgb_bg;
     a.ld_np = ld_normal; a.ld_sem = ld_sem; a.T_thr = T_threshold;
     a.g_rgb = 1.0f / (3.0f * n_rays); a.g_op = lambda_opacity / n_rays; a.g_dist = lambda_distortion / n_rays;
     a.classes = classes; a.n_rays = n_rays; a.total_samples = total_samples; a.vr_samples = vr_samples;

@@ -426,10 +426,9 @@ def _render_rays_train(model, rays_o, rays_d, hits_t, **kwargs):
 
 
 def _fused_tail_ok(model, kwargs, exp_step_factor, classes):
-    """the one-launch render + loss tail covers the default recipe: sigmoid colours (no tone mapper), black background,
-    detached analytic normals, at most 8 classes"""
+    """the one-launch render + loss tail covers the default recipe: sigmoid colours (no tone mapper), black or random
+    constant background (no skybox network), detached analytic normals, at most 8 classes"""
     return (getattr(model, 'rgb_act', 'Sigmoid') == 'Sigmoid' and not kwargs.get('use_skybox', False)
-            and not (exp_step_factor != 0 and kwargs.get('random_bg', False))
             and not getattr(model, 'differentiable_normals', False) and classes <= 8
             and not getattr(model, 'compact_dead_samples', None) and hasattr(model, '_field'))
 
@@ -443,7 +442,7 @@ class _RenderLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, sig, rgb_o, dsig_dx, np_raw, sem_logits, dirs, deltas, ts, rays_a, rgb_gt, scale3, T_thr, classes,
-                lambda_opa, lambda_dist):
+                lambda_opa, lambda_dist, rgb_bg=None):
         n, nr = sig.shape[0], rays_a.shape[0]
         dev = sig.device
         f32 = torch.float32
@@ -454,7 +453,7 @@ class _RenderLossFn(torch.autograd.Function):
         acc = E(8)                                   # [terms (4) | vr_samples (int64) | -]: adjacent, cleared by one memset
         terms, vr = acc[:4], acc[4:6].view(torch.int64)
         call("render_loss_fused", sig, rgb_o, dsig_dx, scale3, np_raw, np_raw.stride(0), sem_logits, sem_logits.stride(0),
-             dirs, deltas, ts, rays_a, rgb_gt, float(T_thr), int(classes), nr, float(lambda_opa), float(lambda_dist),
+             dirs, deltas, ts, rays_a, rgb_gt, rgb_bg, float(T_thr), int(classes), nr, float(lambda_opa), float(lambda_dist),
              total, vr, opacity, depth, rgb, normal, sem, ws, Ro, Rp, terms, d_sig, d_rgb)
         ctx.save_for_backward(d_sig, d_rgb)
         ctx.set_materialize_grads(False)             # no zero-filled gradient tensors for the ten other outputs
@@ -464,15 +463,18 @@ class _RenderLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_terms, *_unused):
         d_sig, d_rgb = ctx.saved_tensors
-        return (d_sig, d_rgb) + (None,) * 13
+        return (d_sig, d_rgb) + (None,) * 14
 
 
 def _render_loss_fused(model, results, xyzs, dirs, rays_a, T_threshold, classes, fused, kwargs):
     sig, rgb_o, dsig_dx, np_raw, sem_logits = model._field(xyzs, dirs, kwargs)
     rgb_gt, lambda_opa, lambda_dist = fused
+    rgb_bg = None
+    if kwargs.get('exp_step_factor', 0.) != 0 and kwargs.get('random_bg', False):
+        rgb_bg = torch.rand(3, device=xyzs.device)      # rendering.py:239 (drawn at the same place in the RNG stream)
     (terms, total, vr, opacity, depth, rgb, normal, sem, ws, Ro, Rp) = _RenderLossFn.apply(
         sig, rgb_o, dsig_dx, np_raw, sem_logits, dirs.contiguous(), results['deltas'], results['ts'], rays_a,
-        rgb_gt.contiguous(), model._inv_span(), T_threshold, classes, lambda_opa, lambda_dist)
+        rgb_gt.contiguous(), model._inv_span(), T_threshold, classes, lambda_opa, lambda_dist, rgb_bg)
     results['sigma'] = sig
     results['xyzs'] = xyzs
     results['vr_samples'] = vr[0]

@@ -1093,6 +1093,62 @@ def test_trainer_unbounded_configs(ngp, cfg):
         assert codes.grad is not None and torch.isfinite(codes.grad).all() and codes.grad.abs().sum() > 0
 
 
+def test_fused_tail_with_random_background_and_codes(ngp):
+    """The one-launch render + loss tail on a Playground-like configuration (scale 8, exponential stepping, appearance
+    codes, random background colour): every result, the loss terms and every gradient (field parameters, appearance
+    codes) against the launch-per-operation route on the same samples and the same background draw."""
+    from ngp_amd.losses import nerf_loss_and_grads, NeRFLoss
+    from ngp_amd.rendering import render
+    from ngp_amd.synthetic import LegoProxy
+    torch.manual_seed(33)
+    model = ngp.networks.NGP(scale=8.0, embed_a=True, embed_a_len=8).to(DEV)
+    G = model.grid_size
+    model.register_buffer("density_grid", torch.zeros(model.cascades, G ** 3, device=DEV))
+    coords = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=DEV)] * 3, indexing="ij"), -1)
+    model.register_buffer("grid_coords", coords.reshape(-1, 3).contiguous())
+    with torch.no_grad():
+        model.xyz_net[2].bias.fill_(1.5)
+    model.update_density_grid(0.01 * 1024 / 3 ** 0.5, warmup=True)
+    scene = LegoProxy(n_images=6, img_wh=(100, 100), device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(34)
+    img, pix = scene.sample_batch(1500, generator=gen)
+    o, d = scene.rays(img, pix)
+    gt = torch.rand(1500, 3, device=DEV, generator=gen)
+    codes = torch.nn.Parameter(torch.randn(6, 8, device=DEV) * 0.1)
+    lam_o, lam_d = NeRFLoss().lambda_opa, NeRFLoss().lambda_distortion
+    params = [p for p in model.parameters() if p.numel() > 0] + [codes]
+    out = {}
+    for fused in (False, True):
+        for p in params:
+            p.grad = None
+        torch.manual_seed(35)                      # same marcher noise, same background colour
+        kw = dict(exp_step_factor=1 / 256, num_classes=7, random_bg=True, embedding_a=codes[img])
+        if fused:
+            res = render(model, o, d, _fused_loss=(gt, lam_o, lam_d), **kw)
+            assert "_loss_terms" in res
+            terms = res.pop("_loss_terms")
+            torch.autograd.backward([terms], [torch.tensor([1.0, 0, 0, 0], device=DEV)])
+        else:
+            res = render(model, o, d, **kw)
+            terms, (d_rgb, d_op, d_ws) = nerf_loss_and_grads(res["rgb"], res["opacity"], res["ws"], res["deltas"], res["ts"],
+                                                            res["rays_a"], gt, lam_o, lam_d)
+            torch.autograd.backward([res["rgb"], res["opacity"], res["ws"]], [d_rgb, d_op, d_ws])
+        out[fused] = (res, N(terms), [None if p.grad is None else N(p.grad).copy() for p in params])
+    ra, ta, ga = out[False]
+    rb, tb, gb = out[True]
+    assert int(ra["total_samples"]) == int(rb["total_samples"]) > 0
+    for k in ("opacity", "depth", "rgb", "normal_pred", "semantic", "ws", "Ro", "Rp"):
+        close(N(rb[k]), N(ra[k]), 2e-5, 2e-6)
+    close(tb, ta, 1e-4, 1e-9)
+    for p, a, b in zip(params, ga, gb):
+        if a is None:
+            assert b is None or not b.any()
+            continue
+        scale = np.abs(a).max()
+        assert np.abs(a - b).max() <= 3e-4 * scale + 1e-12, (tuple(p.shape), np.abs(a - b).max(), scale)
+    assert np.abs(ga[-1]).sum() > 0                # the appearance codes did receive a gradient
+
+
 @pytest.mark.parametrize("embed_a", [False, True])
 def test_field_backward_matches_torch_fp64(ngp, embed_a):
     """The fused node's parameter gradients against an fp64 torch re-implementation of the same
