@@ -62,8 +62,15 @@ struct GemmArgs {
 // v > 20 -> v (torch's threshold); v < -15 -> e^v (1+e^v would round to 1); else log(1+e^v).
 __device__ __forceinline__ float softplus_fast(float v)
 {
-    const float e = __expf(v);
-    return v > 20.0f ? v : (v < -15.0f ? e : __logf(1.0f + e));
+    // raw v_exp_f32 / v_log_f32 (base 2): __expf / __logf wrap them in denormal-range scaling (compare, select, ldexp: ~8 more
+    // vector instructions per element) that a softplus never needs — below v = -87 the result is < 1e-38 either way
+    const float e = __builtin_amdgcn_exp2f(v * 1.4426950408889634f);
+    float l = 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + e);
+    // the logarithm is computed unconditionally and SELECTED: left inside the conditional, hipcc wraps every element of an
+    // epilogue tile in its own exec-mask branch (64 s_and_saveexec / s_cbranch / s_or per tile and wave, with their s_nop padding)
+    asm volatile("" : "+v"(l));
+    const float r = v < -15.0f ? e : l;
+    return v > 20.0f ? v : r;
 }
 
 __device__ __forceinline__ float act_fwd(float v, int act)
@@ -105,7 +112,8 @@ __device__ __forceinline__ float act_grad_from_output(float y, int act)
 __device__ __forceinline__ float act_grad_fast(float y, int act)
 {
     if (act == NGP_ACT_SOFTPLUS) { // 1 - exp(-y) cancels for tiny y: two Taylor terms there (relative error < 2e-7)
-        const float e = __expf(-y), t = y * (1.0f - 0.5f * y);   // both sides evaluated: a select, not a branch
+        // raw v_exp_f32 (base 2): y >= 0, so exp(-y) never needs __expf's denormal-range scaling (~5 more instructions)
+        const float e = __builtin_amdgcn_exp2f(y * -1.4426950408889634f), t = y * (1.0f - 0.5f * y);   // both sides evaluated: a select, not a branch
         return y < 1e-3f ? t : 1.0f - e;
     }
     return act == NGP_ACT_RELU ? (y > 0.0f ? 1.0f : 0.0f) : act_grad_from_output(y, act);
@@ -483,8 +491,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p)
                         const bool up = (li & mask) != 0;
 #pragma unroll
                         for (int j = 0; j < half; j++) {
-                            const float keep = up ? v[j + half] : v[j];
-                            const float send = up ? v[j] : v[j + half];
+                            float lo = v[j], hi = v[j + half];
+                            if constexpr (OGW == 1) asm volatile("" : "+v"(lo), "+v"(hi));   // plain selects (see mlp_stream_fwd_kernel's butterfly)
+                            const float keep = up ? hi : lo;
+                            const float send = up ? lo : hi;
                             v[j] = keep + __shfl_xor(send, mask, 64);
                         }
                     }
@@ -732,8 +742,13 @@ __global__ void __launch_bounds__(512) mlp_stream_fwd_kernel(GemmArgs p, int n_t
                     const bool up = (li & mask) != 0;
 #pragma unroll
                     for (int j = 0; j < half; j++) {
-                        const float keep = up ? v[j + half] : v[j];
-                        const float send = up ? v[j] : v[j + half];
+                        float lo = v[j], hi = v[j + half];
+                        // two plain selects: without the barrier hipcc turns `up ? v[j + half] : v[j]` into an extract with a
+                        // lane-dependent index, i.e. a 15-compare select chain per read (930 vector instructions per tile)
+                        // (one output only: with 4 the compiler emits the plain selects by itself and the barrier costs 5 %)
+                        if constexpr (OGW == 1) asm volatile("" : "+v"(lo), "+v"(hi));
+                        const float keep = up ? hi : lo;
+                        const float send = up ? lo : hi;
                         v[j] = keep + __shfl_xor(send, mask, 64);
                     }
                 }
