@@ -309,7 +309,8 @@ def main():
     # scatter (2) and the clip + Adam sweep (2): 7 of ~55 launches, 14 events per step.  Whichever took most device time per
     # step in the timed region is the `roofline` kernel; the MLP products' figures come from a short untimed pass after it.
     LIVE = ("grid_fwd", "grid_bwd_input", "grid_bwd_param", "adam_step")   # "grid_bwd_param" collects both scatter entry points
-    prof_keys = ("linear_fwd", "linear_bwd_input", "linear_bwd_weight", "mlp_bwd_input", "mlp_bwd_weight", "mlp2_fwd", "sumsq")
+    prof_keys = ("linear_fwd", "linear_bwd_input", "linear_bwd_weight", "mlp_bwd_input", "mlp_bwd_weight", "mlp2_fwd",
+                 "mlp2_fwd_dact", "sumsq")   # (mlp2_fwd_dact = the density head's forward: the same kernel, one more output)
     _lib.PROFILE = {k: [] for k in LIVE + SCATTER_CALLS}
     step_at_start = trainer.global_step
     torch.cuda.synchronize()
@@ -346,7 +347,7 @@ def main():
     # their in-step durations say how the schedule shares the device, the solo ones what the kernel itself does.  Every
     # repetition is timed on its own behind a 1 GiB fill: tables (174 / 588 MB) and activations start in HBM, not in the
     # 256 MiB Infinity Cache (back-to-back replays of one launch read above the HBM peak).
-    solo_keys = SCATTER_CALLS + ("mlp_bwd_input", "mlp_bwd_weight", "mlp2_fwd", "grid_fwd", "grid_bwd_input")
+    solo_keys = SCATTER_CALLS + ("mlp_bwd_input", "mlp_bwd_weight", "mlp2_fwd", "mlp2_fwd_dact", "grid_fwd", "grid_bwd_input")
     solo = {}
     if world == 1 and not args.no_solo:
         extra = 0
@@ -371,7 +372,7 @@ def main():
                     e1.record()
                     torch.cuda.synchronize()
                     reps.append(e0.elapsed_time(e1))
-                key = "grid_bwd_param" if name in SCATTER_CALLS else name
+                key = "grid_bwd_param" if name in SCATTER_CALLS else ("mlp2_fwd" if name == "mlp2_fwd_dact" else name)
                 solo.setdefault(key, []).append((sorted(reps)[1], tuple(x for x in a if isinstance(x, int))))
         del flush
     # multi-GPU readiness: what every rank sent through the backend per step, and behind which HIP stream
@@ -409,6 +410,7 @@ def main():
     prof.update(prof_live)
     # the field calls the scaled entry point, other callers the plain one: one kernel, one entry in the tables
     prof["grid_bwd_param"] = [ev for k in SCATTER_CALLS for ev in prof.pop(k, [])]
+    prof["mlp2_fwd"] = prof.get("mlp2_fwd", []) + prof.pop("mlp2_fwd_dact", [])
     steps_of = lambda name: args.steps if name in LIVE else post_steps
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
