@@ -467,6 +467,9 @@ def main():
             if name.startswith("grid"):
                 ns = [a[N_ARG[name]] for _, a in runs]
                 kern[name]["solo_GBps"] = BYTES_PER_SAMPLE[name] * sum(ns) / (sum(ms) * 1e-3) / 1e9
+                if kern[name]["solo_GBps"] > HBM_PEAK_GBS:
+                    kern[name]["solo_note"] = ("algorithmic bytes (SURVEY §8(d): every corner row of every sample) per second; above the "
+                                               "HBM peak because runs of samples share rows on chip — not an HBM rate, see hbm_bytes_pmc")
             else:
                 sel = [(m, 2.0 * a[5] * a[6] * a[7]) for m, a in runs if min(a[6], a[7]) >= 32]
                 if sel:
