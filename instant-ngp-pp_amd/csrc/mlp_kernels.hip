@@ -928,7 +928,9 @@ __global__ void __launch_bounds__(512) mlp_stream_wgrad_kernel(GemmArgs p, int64
 #define NGP_WGRAD_D 8
 #endif
     constexpr int D = NGP_WGRAD_D;     // steps (of two samples) the operand loads run ahead of the MFMAs
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, grp = threadIdx.x >> 8;
+    // (wave and group numbers as scalars: the chunk bounds, the loop counter and the base pointers then live in SGPRs)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) & 3)),
+              grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     const int li = lane & 31, lh = lane >> 5;
     const bool two = blockDim.x == 512;                  // launched with 4 waves instead: one group, no hand-over
     const int64_t half = two ? chunk / 2 : chunk;        // chunk is a multiple of 32
@@ -981,23 +983,41 @@ __global__ void __launch_bounds__(512) mlp_stream_wgrad_kernel(GemmArgs p, int64
     // store); scheduling barriers keep the loads at the top of the turn and each step's MFMAs in their step.
     f32x4 th0, th1, tx0, tx1;
     float td;
-    auto clamp_row = [&](int64_t s) { return s < kend ? s : kend - 1; };
     const bool d_lane = lane < 16 * XF;
     const int d_s = d_lane ? lane / XF : 0, d_o = d_lane ? lane % XF : 0;
     float* d_slot = sD + (d_lane ? d_s * 4 + d_o : 64 + lane);   // lanes without a dz2 element store to a dummy word
     f32x4 xn[D], xc[D];
+    // Addresses.  Every load of a turn reads row (t0 + k) clamped to the group's last row.  Written with 64-bit rows
+    // (clamp, row * ld, base + 4 * ...) that is ~10 vector instructions per load, three of them quarter-rate integer
+    // multiplies: ~110 of the loop's ~250 vector instructions per turn beside 32 MFMAs.  Instead: scalar base pointers at
+    // the group's first row, 32-bit BYTE offsets relative to them (the launcher keeps chunk * ld * 4 below 2^31), a
+    // per-lane constant part, a scalar part that advances by 16 rows per turn, and the clamp as ONE v_min_u32 against
+    // the lane's offset in the last row (offsets grow with the row for a fixed column).
+    const int64_t row0 = kbeg < kend ? kbeg : kend - 1;                  // (an empty group reads row kend - 1 >= 0, never uses it)
+    const uint32_t rmax = (uint32_t)(kend - 1 - row0);                   // last row, relative
+    const char* const Bb = reinterpret_cast<const char*>(p.B + row0 * p.ldb);
+    const char* const Ab = reinterpret_cast<const char*>(p.A + row0 * p.lda + wave * 32);
+    const char* const Db = reinterpret_cast<const char*>(p.xf_dz2 + row0 * p.xf_lddz2);
+    const uint32_t ldb4 = (uint32_t)p.ldb * 4u, lda4 = (uint32_t)p.lda * 4u, ldd4 = (uint32_t)p.xf_lddz2 * 4u;
+    const uint32_t xo0 = (uint32_t)lh * ldb4 + 16u * li, xmax = rmax * ldb4 + 16u * li;
+    const uint32_t ho0 = (uint32_t)hs * lda4 + 16u * hp, hmax = rmax * lda4 + 16u * hp;
+    const uint32_t x5o = (uint32_t)xs * ldb4 + 512u + 16u * xp, x5max = rmax * ldb4 + 512u + 16u * xp;
+    const uint32_t dof = (uint32_t)d_s * ldd4 + 4u * d_o, dmax = rmax * ldd4 + 4u * d_o;
+    auto umin = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
     auto issue_turn = [&](int64_t t0) {
+        const uint32_t rel = (uint32_t)(t0 - row0);                      // scalar: rows in front of this turn
+        const uint32_t tx = rel * ldb4, th = rel * lda4, tdz = rel * ldd4;
 #pragma unroll
         for (int d = 0; d < D; d++)
-            xn[d] = *reinterpret_cast<const f32x4*>(p.B + clamp_row(t0 + 2 * d + lh) * p.ldb + 4 * li);
-        th0 = *reinterpret_cast<const f32x4*>(p.A + clamp_row(t0 + hs) * p.lda + wave * 32 + 4 * hp);
-        th1 = *reinterpret_cast<const f32x4*>(p.A + clamp_row(t0 + 8 + hs) * p.lda + wave * 32 + 4 * hp);
+            xn[d] = *reinterpret_cast<const f32x4*>(Bb + umin(tx + (uint32_t)(2 * d) * ldb4 + xo0, xmax));
+        th0 = *reinterpret_cast<const f32x4*>(Ab + umin(th + ho0, hmax));
+        th1 = *reinterpret_cast<const f32x4*>(Ab + umin(th + 8u * lda4 + ho0, hmax));
         if (TN > 4) {
-            const float* xr = p.B + clamp_row(t0 + xs) * p.ldb + 128 + 4 * xp;
+            const char* xr = Bb + umin(tx + x5o, x5max);
             tx0 = *reinterpret_cast<const f32x4*>(xr);
-            tx1 = *reinterpret_cast<const f32x4*>(xr + x5_second);   // n_in = 144: the same piece again
+            tx1 = *reinterpret_cast<const f32x4*>(xr + 4 * x5_second);   // n_in = 144: the same piece again
         }
-        td = p.xf_dz2[clamp_row(t0 + d_s) * p.xf_lddz2 + d_o];
+        td = *reinterpret_cast<const float*>(Db + umin(tdz + dof, dmax));
     };
     auto commit_turn = [&](int64_t t0) {
 #pragma unroll
@@ -2045,6 +2065,13 @@ int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t
         int64_t blocks = (int64_t)n_cu * (threads == 512 ? 1 : 2);
         int64_t chunk = ((n + blocks - 1) / blocks + 31) / 32 * 32;
         if (chunk < 128) chunk = 128;
+        {   // the kernel addresses a chunk with 32-bit byte offsets: keep (chunk + 32) rows of the widest operand below 2^31
+            int64_t ldmax = ldx > ldh ? ldx : ldh;
+            if (lddz2 > ldmax) ldmax = lddz2;
+            const int64_t cap = (((int64_t)1 << 31) / (4 * ldmax) - 64) / 32 * 32;
+            if (cap < 128) return NGP_EINVAL;
+            if (chunk > cap) chunk = cap;
+        }
         blocks = (n + chunk - 1) / chunk;
 #define LAUNCH_SW2(XFV, ACTV, TNV, W2GV)                                                                                \
     do {                                                                                                                \
