@@ -615,13 +615,14 @@ __global__ void __launch_bounds__(512) mlp_stream_fwd_kernel(GemmArgs p, int n_t
     float* b1s = W2s + F2 * H;              // [H]
     float* b2s = b1s + H;                   // [F2]  (a global load in the epilogue would drain every older
                                             //        load and store of the wave: vmcnt counts in order)
-    float* stage = b2s + 8;                 // [8 waves][32][32]
-    for (int idx = threadIdx.x; idx < H * (K / 4); idx += 512) {
+    float* stage = b2s + 8;                 // [waves][32][32]
+    const int nthr = blockDim.x, nw = nthr >> 6;   // 8 waves (one workgroup fills a CU's registers) or 4
+    for (int idx = threadIdx.x; idx < H * (K / 4); idx += nthr) {
         const int n = idx / (K / 4), k4 = (idx - n * (K / 4)) * 4;
         const float4 q = *reinterpret_cast<const float4*>(p.B + (int64_t)n * p.ldb + k4);
         *reinterpret_cast<float4*>(Ws + n * LDW + k4) = q;
     }
-    for (int idx = threadIdx.x; idx < F2 * H; idx += 512) {
+    for (int idx = threadIdx.x; idx < F2 * H; idx += nthr) {
         const int o = idx / H, n = idx - o * H;
         W2s[idx] = o < p.f2_nout ? p.f2_W2[o * p.f2_ldw2 + n] : 0.0f;
     }
@@ -631,8 +632,8 @@ __global__ void __launch_bounds__(512) mlp_stream_fwd_kernel(GemmArgs p, int n_t
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int stride = gridDim.x * 8;
-    int tile = blockIdx.x * 8 + wave;
+    const int stride = gridDim.x * nw;
+    int tile = blockIdx.x * nw + wave;
     if (tile >= n_tiles) return;
     f32x4 a[KQ];
     auto row_ptr = [&](int t) {
@@ -792,12 +793,13 @@ __global__ void __launch_bounds__(512) mlp_stream_dgrad_kernel(GemmArgs p, int n
     constexpr int STREAM_VMCNT = KQ - 1 + 12;
     float* Wt = smem;                       // [128 input columns][LDW]: Wt[j][n] = W1[n][j]
     float* W2s = Wt + 128 * LDW;            // [XF][128]
-    float* stage = W2s + XF * 128;          // [8 waves][32][32]
-    for (int idx = threadIdx.x; idx < 128 * 128; idx += 512) {
+    float* stage = W2s + XF * 128;          // [waves][32][32]
+    const int nthr = blockDim.x, nw = nthr >> 6;
+    for (int idx = threadIdx.x; idx < 128 * 128; idx += nthr) {
         const int n = idx >> 7, j = idx & 127;
         Wt[j * LDW + n] = p.B[(int64_t)n * p.ldb + j];
     }
-    for (int idx = threadIdx.x; idx < XF * 128; idx += 512) {
+    for (int idx = threadIdx.x; idx < XF * 128; idx += nthr) {
         const int o = idx >> 7, n = idx & 127;
         W2s[idx] = o < p.xf_nout ? p.xf_W2[o * p.xf_ldw2 + n] : 0.0f;
     }
@@ -805,8 +807,8 @@ __global__ void __launch_bounds__(512) mlp_stream_dgrad_kernel(GemmArgs p, int n
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int stride = gridDim.x * 8;
-    int tile = blockIdx.x * 8 + wave;
+    const int stride = gridDim.x * nw;
+    int tile = blockIdx.x * nw + wave;
     if (tile >= n_tiles) return;
     f32x4 a[KQ];
     float d2[XF];
@@ -1476,9 +1478,11 @@ __global__ void __launch_bounds__(256) mlp_hidden_bwd_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------- optimizer
-__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            int64_t n, float step_size, float beta1, float beta2, float eps, float bc2_sqrt,
-                            float weight_decay, const float* __restrict__ grad_scale, int zero_grad, bool sparse_zero)
+template <int U>   // 16-byte quads per lane and trip
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float step_size, float beta1, float beta2,
+                                                   float eps, float bc2_sqrt, float weight_decay,
+                                                   const float* __restrict__ grad_scale, int zero_grad, bool sparse_zero)
 {
     const float gs = grad_scale ? *grad_scale : 1.0f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1500,20 +1504,20 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     auto nz = [](const float4& q) { return q.x != 0.0f || q.y != 0.0f || q.z != 0.0f || q.w != 0.0f; };
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // two independent 16-B quads per lane and trip: the launch is capped well below full occupancy
-    // (other streams' kernels must be able to get wave slots), so the bytes in flight come from
+    // U independent 16-B quads per lane and trip: the launch is capped well below full occupancy
+    // (other streams' kernels must be able to get wave slots and registers), so the bytes in flight come from
     // the unroll instead of from more waves
-    for (; i + stride < n4; i += 2 * stride) {
-        const int64_t k = i + stride;
-        float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
-        float4 pb = p4[k], gb = g4[k], mb = m4[k], vb = v4[k];
-        update(pa, ga, ma, va);
-        update(pb, gb, mb, vb);
-        p4[i] = pa; m4[i] = ma; v4[i] = va;
-        p4[k] = pb; m4[k] = mb; v4[k] = vb;
-        // untouched table rows (no sample near them this step) already hold zeros: do not write them again
-        if (zero_grad && (sparse_zero ? nz(ga) : true)) g4[i] = zero4;
-        if (zero_grad && (sparse_zero ? nz(gb) : true)) g4[k] = zero4;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        float4 pa[U], ga[U], ma[U], va[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { pa[u] = p4[i + u * stride]; ga[u] = g4[i + u * stride]; ma[u] = m4[i + u * stride]; va[u] = v4[i + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            update(pa[u], ga[u], ma[u], va[u]);
+            p4[i + u * stride] = pa[u]; m4[i + u * stride] = ma[u]; v4[i + u * stride] = va[u];
+            // untouched table rows (no sample near them this step) already hold zeros: do not write them again
+            if (zero_grad && (sparse_zero ? nz(ga[u]) : true)) g4[i + u * stride] = zero4;
+        }
     }
     for (; i < n4; i += stride) {
         float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
@@ -1817,7 +1821,8 @@ static int mlp2_fwd_impl(const float* x, int64_t ldx, const float* W1, int64_t l
         // sits in (the test-time renderer's two loops are compared bit for bit)
         const int n_tiles = (int)((n + 31) / 32);
         const int f2 = n_out == 1 ? 1 : (n_out <= 4 ? 4 : 8);
-        const size_t lds = (size_t)(H * (n_in + 4) + f2 * H + H + 8 + 8 * 1024) * sizeof(float);
+        static const int nw = (int)ab_long("NGP_MLP_NW_FWD", ab_long("NGP_MLP_NW", 8));   // waves per workgroup (A/B: 4)
+        const size_t lds = (size_t)(H * (n_in + 4) + f2 * H + H + 8 + nw * 1024) * sizeof(float);
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
@@ -1827,7 +1832,7 @@ static int mlp2_fwd_impl(const float* x, int64_t ldx, const float* W1, int64_t l
         }
         // one workgroup per CU for the 128-wide layers (W1 takes half the LDS), two for the 32-wide heads
         const int max_blocks = n_cu * (H == 128 ? 1 : 2);
-        const int blocks = (n_tiles + 7) / 8 < max_blocks ? (n_tiles + 7) / 8 : max_blocks;
+        const int blocks = (n_tiles + nw - 1) / nw < max_blocks ? (n_tiles + nw - 1) / nw : max_blocks;
 #define LAUNCH_STREAM(F2V, KQV, ACTV, TNV)                                                                              \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
@@ -1837,7 +1842,7 @@ static int mlp2_fwd_impl(const float* x, int64_t ldx, const float* W1, int64_t l
                 return NGP_ELAUNCH;                                                                                     \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL((mlp_stream_fwd_kernel<F2V, KQV, ACTV, TNV>), dim3(blocks), dim3(512), lds, st, p, n_tiles); \
+        hipLaunchKernelGGL((mlp_stream_fwd_kernel<F2V, KQV, ACTV, TNV>), dim3(blocks), dim3(64 * nw), lds, st, p, n_tiles); \
     } while (0)
 #define LAUNCH_STREAM_A(F2V, KQV, TNV)                                                                                  \
     do {                                                                                                                \
@@ -1995,18 +2000,19 @@ int ngp_mlp_bwd_input(const float* dz2, int64_t lddz2, const float* W2, int64_t 
             if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NGP_ELAUNCH;
             n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
-        const int blocks = (n_tiles + 7) / 8 < n_cu ? (n_tiles + 7) / 8 : n_cu;
+        static const int nw = (int)ab_long("NGP_MLP_NW_DGRAD", ab_long("NGP_MLP_NW", 8));
+        const int blocks = (n_tiles + nw - 1) / nw < n_cu ? (n_tiles + nw - 1) / nw : n_cu;
 #define LAUNCH_SD(XFV, ACTV)                                                                                            \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
-        const size_t lds = (size_t)(128 * 132 + XFV * 128 + 8 * 1024) * sizeof(float);                                  \
+        const size_t lds = (size_t)(128 * 132 + XFV * 128 + nw * 1024) * sizeof(float);                                 \
         if (!attr_set) {                                                                                                \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_stream_dgrad_kernel<XFV, ACTV>),                 \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)              \
                 return NGP_ELAUNCH;                                                                                     \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL((mlp_stream_dgrad_kernel<XFV, ACTV>), dim3(blocks), dim3(512), lds, st, p, n_tiles);         \
+        hipLaunchKernelGGL((mlp_stream_dgrad_kernel<XFV, ACTV>), dim3(blocks), dim3(64 * nw), lds, st, p, n_tiles);    \
     } while (0)
 #define LAUNCH_SD_A(XFV)                                                                                                \
     do {                                                                                                                \
@@ -2057,12 +2063,17 @@ int ngp_mlp_bwd_weight(const float* dz2, int64_t lddz2, const float* W2, int64_t
             if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NGP_ELAUNCH;
             n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
-        // 8 waves per CU either way: one workgroup of 8 (two groups meeting in LDS, half the atomics) for the
-        // 128-column case, two workgroups of 4 for the 144 / 160-column case (measured: 0.236 -> 0.225 ms and
-        // 0.313 -> 0.331 ms respectively with 8); a group's share of the chunk is a multiple of the 16 samples
-        // one turn of the prefetch ring covers
-        const int threads = n_in == 128 ? 512 : 256;
-        int64_t blocks = (int64_t)n_cu * (threads == 512 ? 1 : 2);
+        // The kernel takes workgroups of 8 waves (two groups meeting in LDS, half the atomics; alone the faster shape
+        // for the 128-column case: 0.236 -> 0.225 ms) or of 4; a group's share of the chunk is a multiple of the 16
+        // samples one turn of the prefetch ring covers
+        // ONE 4-wave workgroup per CU (a wave per SIMD): alone the kernel is ~10 % slower than with 8 waves per CU
+        // (0.38 -> 0.41-0.43 ms in the step), but it runs beside the gradient scatter, and what the scatter's waves
+        // get of the CU is worth more to the step (-2.5 %, profiles/r03_occupancy_shaping.txt); NGP_WGRAD_WPC=9: the
+        // round's earlier shape (8 waves per CU) for the A/B
+        static const int wpc_env = (int)ab_long("NGP_WGRAD_WPC", 1);
+        const int wpc = wpc_env == 9 ? 0 : wpc_env;
+        const int threads = (n_in == 128 && !wpc) ? 512 : 256;
+        int64_t blocks = (int64_t)n_cu * (wpc ? wpc : (threads == 512 ? 1 : 2));
         int64_t chunk = ((n + blocks - 1) / blocks + 31) / 32 * 32;
         if (chunk < 128) chunk = 128;
         {   // the kernel addresses a chunk with 32-bit byte offsets: keep (chunk + 32) rows of the widest operand below 2^31
@@ -2129,15 +2140,24 @@ int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    // 2 workgroups per CU: 5.2 TB/s alone (2048: 4.5) and leaves wave slots to other streams
-    static const int64_t cap = ab_long("NGP_ADAM_BLOCKS", 512);
+    // ONE workgroup per CU, a wave per SIMD with 64 registers: the sweep runs beside the next step's density path (hash-grid
+    // gather, MLP forward with its 2 x 208 registers per SIMD, analytic-normal passes), and those find room on every CU.  With 2
+    // workgroups per CU the sweep alone is faster (5.2 TB/s; 2048 workgroups: 4.5) and the step slower: the 8-wave MLP workgroups
+    // then wait for whole CUs to drain (profiles/r03_occupancy_shaping.txt: -2 % per step with 256)
+    static const int64_t cap = ab_long("NGP_ADAM_BLOCKS", 256);
     int64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > cap) blocks = cap;
     static const bool sparse_zero = !ab_flag("NGP_ADAM_DENSE_ZERO");
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, step_size, beta1, beta2, eps, bc2_sqrt, weight_decay, grad_scale, zero_grad,
-                       sparse_zero);
+    static const int unroll = (int)ab_long("NGP_ADAM_UNROLL", 2);
+#define LAUNCH_ADAM(U)                                                                                                  \
+    hipLaunchKernelGGL(adam_kernel<U>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, \
+                       exp_avg_sq, n, step_size, beta1, beta2, eps, bc2_sqrt, weight_decay, grad_scale, zero_grad,      \
+                       sparse_zero)
+    if (unroll == 4) LAUNCH_ADAM(4);
+    else if (unroll == 3) LAUNCH_ADAM(3);
+    else LAUNCH_ADAM(2);
+#undef LAUNCH_ADAM
     return ngp_check_launch();
 }
 

@@ -286,8 +286,11 @@ class _FieldFn(Function):
         K = 144 + E
         Kp = model.rgb_net.padded_in
         span = model._span()
-        xn = (x - model.xyz_min).div_(span)   # (before the wait below: it reads no parameter and runs under the Adam sweep)
-        _wait_params(model, rgb_table=False)
+        xn = (x - model.xyz_min).div_(span)   # (before the waits below: it reads no parameter and runs under the Adam sweep)
+        # the two pieces of the trainer's Adam sweep (or of the sharded optimizer's all-gather): every stream below waits
+        # for a piece where it first reads that piece's parameters
+        ev_p, ev_c = getattr(model, "_params_ready", None), getattr(model, "_rgb_params_ready", None)
+        model._params_ready = model._rgb_params_ready = None
         # Samples behind their ray's early-termination point take no part in the image and get no gradient: when the
         # renderer hands over the rays' segments (model._live_ctx), the colour branch and its backward run on the
         # live samples only.  The density head needs every sample (the stop depends on sigma); the list of live rows
@@ -333,8 +336,11 @@ class _FieldFn(Function):
                 xn, d = bufs["xn_full"], bufs["d_full"]
                 rgb_o, np_o, sem_o = bufs["rgb_o"], bufs["np_o"], bufs["sem_o"]
             call("sh_fwd_dirs", d, n, 4, rgb_in, Kp)
-            _wait_params(model)   # the colour table's Adam piece (the stream this runs on waits for it)
+            if ev_c is not None:
+                ev_c.wait()   # the colour table's piece (the stream this runs on waits for it)
             call("grid_fwd", re.desc, rgb_table, xn, n, rgb_in[:, 16:], Kp)
+            if ev_p is not None:
+                ev_p.wait()   # the MLPs' piece
             if E:
                 rgb_in[:, 144:K] = embed_a
             if Kp > K:
@@ -373,6 +379,8 @@ class _FieldFn(Function):
                 colour_branch()
 
         # density head
+        if ev_p is not None:
+            ev_p.wait()
         call("grid_fwd", xe.desc, xyz_table, xn, n, feat, 128)
         if _FUSED_FWD and _FUSED_BWD:
             # both layers in one launch, the 1-wide second layer in the MFMA epilogue, which also leaves

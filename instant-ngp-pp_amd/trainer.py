@@ -417,7 +417,7 @@ class NGPTrainer:
                     self.norm_acc.zero_()
                 # two pieces: [density table | MLPs] first — the next forward starts on them — then
                 # the colour table, which the field does not read before its colour branch
-                events = []
+                events = {}
                 for lo, hi in ((b0, n), (0, b0)):
                     if hi > lo:
                         call("adam_step", self.flat_param[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi],
@@ -425,7 +425,7 @@ class NGPTrainer:
                              self.scalars[1:2], 1)
                     ev = torch.cuda.Event()
                     ev.record(side)
-                    events.append(ev)
+                    events[lo] = ev
                 if zero_after:
                     self.scalars[0:1].zero_()
                     self.norm_acc.zero_()
@@ -433,7 +433,7 @@ class NGPTrainer:
                     ev = torch.cuda.Event()
                     ev.record(side)
                     self.model._acc_zeroed = ev
-            self.model._params_ready, self.model._rgb_params_ready = events
+            self.model._params_ready, self.model._rgb_params_ready = events[b0], events[0]
             return
         self.scalars.zero_()
         # sharded: bucket 0's reduce-scatter was issued from the colour encoder's backward
