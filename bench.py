@@ -572,6 +572,16 @@ def main():
             if sms > 0:
                 mlp["solo"] = {"achieved": sfl / (sms * 1e-3) / 1e12, "frac": sfl / (sms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                "ms_per_step": sms, "note": "the same launches replayed alone on an idle device"}
+        # the whole step against its byte floor: 9,216 B/sample for the two gathers, 9,216 for the two scatters,
+        # 4,620 for the analytic-normal gather, 28 B per parameter for clip + Adam (one rank's share of the samples and, when the
+        # optimizer is sharded, of the parameters)
+        n_param = sum(p.numel() for p in model.parameters())
+        step_bytes = 23052.0 * (total_samples / world) / args.steps + 28.0 * n_param / (world if world > 1 else 1)
+        step_level = {"algorithmic_bytes_per_step": step_bytes, "GBps": step_bytes / (elapsed / args.steps) / 1e9,
+                      "frac_of_hbm_peak": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                      "note": "23,052 B per sample (hash-grid gathers, scatters, analytic-normal gather: SURVEY 8(d)) + 28 B per "
+                              "parameter (clip + Adam) over ms_per_step; activations (MLP inputs / hidden layers, ~8 KB per "
+                              "sample) are not in the floor"}
         out = {
             "metric": "train rays/sec", "value": rays_total / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -595,6 +605,7 @@ def main():
                                      "under the last warm-up step) and runs every other stage of all of them",
                        "parallelism": f"ray-batch dp{world}"},
             "roofline": roofline,
+            "step_level": step_level,
             "mlp_mfma": mlp,
             "comm": comm,
             "kernels": kern,
