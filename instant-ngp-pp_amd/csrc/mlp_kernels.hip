@@ -2154,9 +2154,13 @@ int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
     hipLaunchKernelGGL(adam_kernel<U>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, \
                        exp_avg_sq, n, step_size, beta1, beta2, eps, bc2_sqrt, weight_decay, grad_scale, zero_grad,      \
                        sparse_zero)
+#ifdef NGP_AB_VARIANTS
     if (unroll == 4) LAUNCH_ADAM(4);
     else if (unroll == 3) LAUNCH_ADAM(3);
-    else LAUNCH_ADAM(2);
+    else
+#endif
+        LAUNCH_ADAM(2);
+    (void)unroll;
 #undef LAUNCH_ADAM
     return ngp_check_launch();
 }
