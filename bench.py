@@ -524,7 +524,7 @@ def main():
                               "atomic REQUEST rate (one request per 64-byte line a wave-instruction touches, 20 G/s "
                               "measured: profiles/r02_atomic_shapes.txt), see `atomic_requests`; line-aligned run merging + "
                               "zero skipping cut the real traffic to `traffic` bytes per launch",
-            "adam_step": "clip + Adam sweep over all 200 M parameters: p, g, m, v read, p, m, v written; launched one wave per SIMD so that the next step's density path (gather, 8-wave MLP workgroups) runs beside it on every CU: slower alone, faster per step (profiles/r03_occupancy_shaping.txt)",
+            "adam_step": "clip + Adam sweep over all 200 M parameters: p, g, m, v read, p, m, v written; the next step's density gather runs beside it",
         }
 
         def roof(name):

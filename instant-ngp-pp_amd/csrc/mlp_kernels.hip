@@ -2140,11 +2140,12 @@ int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    // ONE workgroup per CU, a wave per SIMD with 64 registers: the sweep runs beside the next step's density path (hash-grid
-    // gather, MLP forward with its 2 x 208 registers per SIMD, analytic-normal passes), and those find room on every CU.  With 2
-    // workgroups per CU the sweep alone is faster (5.2 TB/s; 2048 workgroups: 4.5) and the step slower: the 8-wave MLP workgroups
-    // then wait for whole CUs to drain (profiles/r03_occupancy_shaping.txt: -2 % per step with 256)
-    static const int64_t cap = ab_long("NGP_ADAM_BLOCKS", 256);
+    // 2 workgroups per CU (a wave per SIMD each, 64 registers): 5.2 TB/s alone (2048 workgroups: 4.5) and room on every CU for
+    // the next step's density path, which runs beside the sweep.  ONE workgroup per CU lets the 8-wave MLP workgroups of that path
+    // in at once (the sweep then runs at 0.87-0.92 instead of 0.82 ms per launch in the step): -2 % per step in bench.py's loop
+    // before the weight gradient was reshaped, nothing after, and +3 % in a loop that also loads its batches
+    // (tools/train_dataset.py): profiles/r03_occupancy_shaping.txt (1), (9)
+    static const int64_t cap = ab_long("NGP_ADAM_BLOCKS", 512);
     int64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > cap) blocks = cap;
