@@ -1831,7 +1831,8 @@ static int mlp2_fwd_impl(const float* x, int64_t ldx, const float* W1, int64_t l
             n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
         // one workgroup per CU for the 128-wide layers (W1 takes half the LDS), two for the 32-wide heads
-        const int max_blocks = n_cu * (H == 128 ? 1 : 2);
+        static const int wg_rounds_f = (int)ab_long("NGP_MLP_WG_ROUNDS_FWD", ab_long("NGP_MLP_WG_ROUNDS", 1));   // A/B: k workgroups per CU, one after the other
+        const int max_blocks = n_cu * (H == 128 ? 1 : 2) * wg_rounds_f;
         const int blocks = (n_tiles + nw - 1) / nw < max_blocks ? (n_tiles + nw - 1) / nw : max_blocks;
 #define LAUNCH_STREAM(F2V, KQV, ACTV, TNV)                                                                              \
     do {                                                                                                                \
@@ -2001,7 +2002,9 @@ int ngp_mlp_bwd_input(const float* dz2, int64_t lddz2, const float* W2, int64_t 
             n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
         static const int nw = (int)ab_long("NGP_MLP_NW_DGRAD", ab_long("NGP_MLP_NW", 8));
-        const int blocks = (n_tiles + nw - 1) / nw < n_cu ? (n_tiles + nw - 1) / nw : n_cu;
+        static const int wg_rounds_d = (int)ab_long("NGP_MLP_WG_ROUNDS_DGRAD", ab_long("NGP_MLP_WG_ROUNDS", 1));
+        const int cap_d = n_cu * wg_rounds_d;
+        const int blocks = (n_tiles + nw - 1) / nw < cap_d ? (n_tiles + nw - 1) / nw : cap_d;
 #define LAUNCH_SD(XFV, ACTV)                                                                                            \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
