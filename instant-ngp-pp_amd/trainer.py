@@ -319,13 +319,18 @@ class NGPTrainer:
                                       warmup=self.global_step < self.warmup_steps)
         ahead = self._march_ahead
         marched = None
+        launch_next_late = False
         if ahead is not None and next_rays is not None:
             marched = ahead.take(rays_o, rays_d, self.exp_step_factor)
-            if marched is None:   # nothing in flight for this batch: march it now, same route
+            late = marched is None
+            if late:   # nothing in flight for this batch: march it now, same route
                 ahead.launch(model, rays_o, rays_d, self.exp_step_factor)
                 marched = ahead.take(rays_o, rays_d, self.exp_step_factor)
             if (self.global_step + 1) % self.update_interval != 0:
-                ahead.launch(model, next_rays[0], next_rays[1], self.exp_step_factor)
+                if late:   # the host has just waited for this batch's march (a step that starts with an occupancy update): the
+                    launch_next_late = True   # device is idle until the forward is enqueued - the next batch's march goes behind it
+                else:
+                    ahead.launch(model, next_rays[0], next_rays[1], self.exp_step_factor)
         elif ahead is not None:
             marched = ahead.take(rays_o, rays_d, self.exp_step_factor)
         default_recipe = bool(self.fused_loss and not loss_kwargs and not target)
@@ -335,6 +340,8 @@ class NGPTrainer:
             extra['_fused_loss'] = (rgb_gt, self.loss_fn.lambda_opa, self.loss_fn.lambda_distortion)
         results = render(model, rays_o, rays_d, exp_step_factor=self.exp_step_factor,
                          num_classes=self.num_classes, marched=marched, **self.render_kwargs, **extra)
+        if launch_next_late:
+            ahead.launch(model, next_rays[0], next_rays[1], self.exp_step_factor)
         self._norm_share_armed, self._norm_share_fired = True, 0   # one backward follows, then the optimizer step
         # clip_grad_norm_(50) from an upper bound of the norm (ngp_clip_decide) instead of the 0.8 GB sum-of-squares
         # pass: only on the default recipe, where the fused field backward is the one writer of the table gradients
