@@ -291,9 +291,22 @@ def main():
             print("step host ms:", dt, "gc:", gc.get_count(), gc.get_stats()[-1], file=sys.stderr)
         return tot_samples, last
 
+    tuning = trainer.adam_width is None and not trainer.sharded
+    if tuning:
+        trainer.adam_tune = (1 << 60, trainer.adam_tune[1])   # not during the setup below: its loop renders fresh ground truth every step
     for _ in range(args.pretrain):  # setup: fresh rays every step, not part of warm-up or timing
         o, d, gt = next_batch()
         trainer.step(o, d, gt)
+    if tuning:
+        # the trainer times its two Adam launch widths in windows of 16 steps and keeps the faster one (NGPTrainer.__init__);
+        # a training run does that once, at steps 320-448 of its own loop — here it happens in THIS loop's regime (resident
+        # batches, march-ahead), still as untimed setup, before the warm-up and the timed region
+        first = -(-trainer.global_step // trainer.update_interval) * trainer.update_interval
+        trainer.adam_tune = (first, trainer.adam_tune[1])
+        n_tune = first - trainer.global_step + 2 * trainer.adam_tune[1] * trainer.update_interval + 4
+        run(n_tune, 0, True)
+        torch.cuda.synchronize()
+        run(4, n_tune, True)   # (the measurement is read once its last event has completed)
     # the interpreter's full collections walk every live object (modules, the 64 ray batches, ...): ~60 ms,
     # once every few hundred steps, with the GPU draining meanwhile.  Objects alive now live for the whole
     # run: move them out of the collector's sight (what a long-running training loop does as well).
@@ -603,6 +616,8 @@ def main():
                        "pipelining": "steady state: batch i+1 is marched on a side stream under step i, so the timed "
                                      f"region marches {args.steps - 1} of its {args.steps} batches (the first was marched "
                                      "under the last warm-up step) and runs every other stage of all of them",
+                       "adam_sweep_workgroups": trainer.adam_width,   # chosen by the trainer's own measurement (None: still measuring / sharded)
+                       "adam_sweep_ms_per_window": getattr(trainer, "adam_tune_ms", None),
                        "parallelism": f"ray-batch dp{world}"},
             "roofline": roofline,
             "step_level": step_level,

@@ -474,6 +474,15 @@ int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
                   int64_t step, const float* grad_scale /* device scalar or NULL */,
                   int zero_grad, void* stream);
 
+/* the same with the launch width named: a grid-stride sweep on `workgroups` workgroups of 256 threads (0: the default, 2 per
+ * CU = 512 on MI355X).  The result does not depend on it; what does is how the sweep shares the CUs with kernels on other
+ * streams — one workgroup per CU leaves room for 8-wave MLP workgroups beside it, two finish the sweep sooner; which is
+ * faster per step depends on the loop around it, so the trainer measures. */
+int ngp_adam_step_width(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        float lr, float beta1, float beta2, float eps, float weight_decay,
+                        int64_t step, const float* grad_scale /* device scalar or NULL */,
+                        int zero_grad, int workgroups, void* stream);
+
 /* sum of squares of a flat tensor accumulated into *out (device scalar; caller zeroes) */
 int ngp_sumsq(const float* x, int64_t n, float* out, void* stream);
 

@@ -2135,7 +2135,15 @@ int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
                   float beta2, float eps, float weight_decay, int64_t step, const float* grad_scale, int zero_grad,
                   void* stream)
 {
-    if (n < 0 || step < 1) return NGP_EINVAL;
+    return ngp_adam_step_width(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                               zero_grad, 0, stream);
+}
+
+int ngp_adam_step_width(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int64_t step, const float* grad_scale, int zero_grad,
+                        int workgroups, void* stream)
+{
+    if (n < 0 || step < 1 || workgroups < 0) return NGP_EINVAL;
     if (n == 0) return NGP_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq) return NGP_EINVAL;
     if (!aligned16(param) || !aligned16(grad) || !aligned16(exp_avg) || !aligned16(exp_avg_sq)) return NGP_EINVAL;
@@ -2143,12 +2151,13 @@ int ngp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    // 2 workgroups per CU (a wave per SIMD each, 64 registers): 5.2 TB/s alone (2048 workgroups: 4.5) and room on every CU for
-    // the next step's density path, which runs beside the sweep.  ONE workgroup per CU lets the 8-wave MLP workgroups of that path
-    // in at once (the sweep then runs at 0.87-0.92 instead of 0.82 ms per launch in the step): -2 % per step in bench.py's loop
-    // before the weight gradient was reshaped, nothing after, and +3 % in a loop that also loads its batches
-    // (tools/train_dataset.py): profiles/r03_occupancy_shaping.txt (1), (9)
-    static const int64_t cap = ab_long("NGP_ADAM_BLOCKS", 512);
+    // Default 2 workgroups per CU (a wave per SIMD each, 64 registers): 5.2 TB/s alone (2048 workgroups: 4.5) and the sweep ends
+    // soonest.  ONE workgroup per CU lets the 8-wave MLP workgroups of the next step's density path in beside it (the sweep then
+    // takes 1.5-1.7 instead of 1.1-1.4 ms, the colour chain follows alone).  Which is faster per step depends on the loop and
+    // the box (+-3 %: profiles/r03_occupancy_shaping.txt (1), (9)), so the caller may name the width:
+    // NGPTrainer times both in its own loop and keeps the faster one.
+    static const int64_t cap_default = ab_long("NGP_ADAM_BLOCKS", 512);
+    const int64_t cap = workgroups > 0 ? workgroups : cap_default;
     int64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > cap) blocks = cap;

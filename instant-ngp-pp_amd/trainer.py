@@ -185,6 +185,17 @@ class NGPTrainer:
         self.update_interval = 16
         self.global_step = 0
         self.group = group
+        # Launch width of the Adam sweep (ngp_adam_step_width): how the sweep shares the CUs with the next step's density path
+        # decides a few per cent of the step, and which width wins depends on the loop around the trainer (resident batches
+        # or a loader at the head of every step) and on the box.  None = measure: after the all-cells
+        # warm-up, windows of `update_interval` steps alternate between the candidates (4 windows each, timed with HIP
+        # events on the optimizer stream, no host synchronisation), then the faster one stays.  The result of a step does
+        # not depend on the width.  NGP_ADAM_WIDTH=<n> / adam_width=<n> fixes it.
+        w = os.environ.get("NGP_ADAM_WIDTH", "")
+        self.adam_width = int(w) if w.isdigit() else None
+        self.adam_candidates = (512, 256)
+        self.adam_tune = (320, 4)            # first step of the measurement, windows per candidate
+        self._tune_events, self._tune_widths = [], []
         self._grad_zeroed = None
         self._flatten()
         # NGP_SERIAL_OPT=1 (A/B): clip + Adam on the caller's stream instead of the optimizer stream
@@ -378,6 +389,36 @@ class NGPTrainer:
         self.optimizer_step()
         return loss.detach(), results
 
+    def _adam_width_now(self, stream):
+        """the sweep's launch width for this step; runs the measurement described in __init__ while it lasts"""
+        if self.adam_width is not None:
+            return self.adam_width
+        start, rounds = self.adam_tune
+        W, cands = self.update_interval, self.adam_candidates
+        k = self.global_step - 1 - start          # (global_step was advanced already: 1-based here)
+        n_win = rounds * len(cands)
+        if k < 0:
+            return cands[0]
+        if k % W == 0 and k // W <= n_win and len(self._tune_events) == k // W:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)                      # window boundary: the same point of every step, on the optimizer stream
+            self._tune_events.append(ev)
+        if k < n_win * W:
+            return cands[(k // W) % len(cands)]
+        if len(self._tune_events) == n_win + 1 and self._tune_events[-1].query():
+            ms = [a.elapsed_time(b) for a, b in zip(self._tune_events, self._tune_events[1:])]
+            med = []
+            for c in range(len(cands)):
+                v = sorted(ms[c::len(cands)])
+                med.append(0.5 * (v[(len(v) - 1) // 2] + v[len(v) // 2]))
+            best = min(range(len(cands)), key=lambda c: med[c])
+            # the default keeps its place unless another width is faster by more than the windows' own spread
+            self.adam_width = cands[best] if med[best] < 0.99 * med[0] else cands[0]
+            self.adam_tune_ms = dict(zip(cands, med))
+            self._tune_events = []
+            return self.adam_width
+        return cands[0]
+
     def optimizer_step(self):
         world = self.buckets.world
         self.global_step += 1
@@ -425,11 +466,12 @@ class NGPTrainer:
                 # two pieces: [density table | MLPs] first — the next forward starts on them — then
                 # the colour table, which the field does not read before its colour branch
                 events = {}
+                width = self._adam_width_now(side)
                 for lo, hi in ((b0, n), (0, b0)):
                     if hi > lo:
-                        call("adam_step", self.flat_param[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi],
+                        call("adam_step_width", self.flat_param[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi],
                              self.exp_avg_sq[lo:hi], hi - lo, float(lr), 0.9, 0.999, 1e-8, 0.0, self.global_step,
-                             self.scalars[1:2], 1)
+                             self.scalars[1:2], 1, width)
                     ev = torch.cuda.Event()
                     ev.record(side)
                     events[lo] = ev

@@ -770,6 +770,49 @@ def test_mlp2_fwd_fused(ngp, case):
     assert torch.equal(dact, want)
 
 
+def test_adam_width_entry_and_trainer_measurement(ngp):
+    """ngp_adam_step_width: the result does not depend on the launch width; NGPTrainer's measurement of the two
+    candidates ends with one of them and both window medians recorded"""
+    n = 300007
+    torch.manual_seed(3)
+    p0, g0 = torch.randn(n, device=DEV), torch.randn(n, device=DEV)
+    outs = []
+    for width in (0, 256, 512, 7):
+        p, g, m, v = p0.clone(), g0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        ngp._lib.call("adam_step_width", p, g, m, v, n, 1e-2, 0.9, 0.999, 1e-8, 0.0, 1, None, 1, width)
+        assert not g.any()
+        outs.append((p, m, v))
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+    from ngp_amd.networks import NGP
+    from ngp_amd.synthetic import LegoProxy
+    from ngp_amd.trainer import NGPTrainer
+    torch.manual_seed(20220806)
+    model = NGP(scale=0.5).to(DEV)
+    G = model.grid_size
+    model.register_buffer("density_grid", torch.zeros(model.cascades, G ** 3, device=DEV))
+    coords = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=DEV)] * 3, indexing="ij"), -1)
+    model.register_buffer("grid_coords", coords.reshape(-1, 3).contiguous())
+    scene = LegoProxy(img_wh=(200, 200), device=DEV)
+    tr = NGPTrainer(model, lr=1e-2)
+    if tr.adam_width is not None:
+        pytest.skip("NGP_ADAM_WIDTH fixes the width")
+    tr.adam_tune = (16, 2)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    for i in range(16 + 2 * 2 * 16 + 8):
+        img, pix = scene.sample_batch(1024, generator=gen)
+        o, d = scene.rays(img, pix)
+        gt, _ = scene.ground_truth(o, d, n_quad=64)
+        loss, _ = tr.step(o, d, gt)
+        if i % 16 == 15:
+            torch.cuda.synchronize()
+    tr.wait()
+    torch.cuda.synchronize()
+    assert tr.adam_width in tr.adam_candidates
+    assert set(tr.adam_tune_ms) == set(tr.adam_candidates) and all(v > 0 for v in tr.adam_tune_ms.values())
+    assert torch.isfinite(loss)
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 1023, 100003, 4_000_001])
 def test_sumsq_and_clip_coef(ngp, n):
     """global gradient norm + clip coefficient (torch.nn.utils.clip_grad_norm_ semantics), aligned and
