@@ -40,6 +40,7 @@ ATOMIC_REQ_PEAK = 20.0e9    # memory-side 64-byte atomic requests/s (tools/atomi
 
 N_ARG = {"grid_fwd": 0, "grid_bwd_param": 1, "grid_bwd_input": 1}  # position of `n` among the int arguments
 SCATTER_CALLS = ("grid_bwd_param", "grid_bwd_param_scaled")   # entry points of the table scatter (same kernel)
+ADAM_CALLS = ("adam_step", "adam_step_width")                   # entry points of the clip + Adam sweep (same kernel)
 
 
 def parse():
@@ -324,7 +325,7 @@ def main():
     LIVE = ("grid_fwd", "grid_bwd_input", "grid_bwd_param", "adam_step")   # "grid_bwd_param" collects both scatter entry points
     prof_keys = ("linear_fwd", "linear_bwd_input", "linear_bwd_weight", "mlp_bwd_input", "mlp_bwd_weight", "mlp2_fwd",
                  "mlp2_fwd_dact", "sumsq")   # (mlp2_fwd_dact = the density head's forward: the same kernel, one more output)
-    _lib.PROFILE = {k: [] for k in LIVE + SCATTER_CALLS}
+    _lib.PROFILE = {k: [] for k in LIVE + SCATTER_CALLS + ADAM_CALLS}
     step_at_start = trainer.global_step
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -423,6 +424,7 @@ def main():
     prof.update(prof_live)
     # the field calls the scaled entry point, other callers the plain one: one kernel, one entry in the tables
     prof["grid_bwd_param"] = [ev for k in SCATTER_CALLS for ev in prof.pop(k, [])]
+    prof["adam_step"] = [ev for k in ADAM_CALLS for ev in prof.pop(k, [])]
     prof["mlp2_fwd"] = prof.get("mlp2_fwd", []) + prof.pop("mlp2_fwd_dact", [])
     steps_of = lambda name: args.steps if name in LIVE else post_steps
 

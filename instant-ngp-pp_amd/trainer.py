@@ -399,6 +399,9 @@ class NGPTrainer:
         n_win = rounds * len(cands)
         if k < 0:
             return cands[0]
+        if not self._tune_events and k > 0:        # the start was missed (a resumed run): begin at the next window boundary
+            self.adam_tune = (-(-(self.global_step - 1) // W) * W, rounds)
+            return cands[0]
         if k % W == 0 and k // W <= n_win and len(self._tune_events) == k // W:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(stream)                      # window boundary: the same point of every step, on the optimizer stream
