@@ -318,3 +318,56 @@ def test_product_library_reads_no_environment(ngp):
     ngp._lib.load()
     out = subprocess.check_output(["nm", "-D", ngp._lib.LIB_PATH], text=True)
     assert "getenv" not in out
+
+
+def test_adam_width_measurement_state_machine(ngp, monkeypatch):
+    """NGPTrainer._adam_width_now without a GPU (events faked): windows of `update_interval` steps alternate between the
+    candidates, one event per window boundary, the faster width stays — the default keeps its place on a tie — and a run
+    that resumes past the start begins at the next window boundary"""
+    import ngp_amd  # noqa: F401
+    from ngp_amd.trainer import NGPTrainer
+
+    clock = {"t": 0.0, "cost": {512: 1.0, 256: 1.0}, "width": 512}
+
+    class FakeEvent:
+        def __init__(self, enable_timing=False):
+            self.t = None
+
+        def record(self, stream=None):
+            self.t = clock["t"]
+
+        def query(self):
+            return True
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+
+    def drive(first_step, n_steps, start, rounds, cost):
+        tr = NGPTrainer.__new__(NGPTrainer)
+        tr.adam_width, tr.adam_candidates, tr.adam_tune = None, (512, 256), (start, rounds)
+        tr._tune_events, tr.update_interval = [], 16
+        clock["t"], clock["cost"] = 0.0, cost
+        seen = []
+        for gs in range(first_step, first_step + n_steps):
+            tr.global_step = gs
+            w = tr._adam_width_now(None)
+            seen.append(w)
+            clock["t"] += cost[w]          # a step with this width takes this long
+        return tr, seen
+
+    tr, seen = drive(1, 200, 32, 2, {512: 1.0, 256: 0.9})
+    assert seen[:32] == [512] * 32                                   # before the measurement: the default
+    assert seen[32:48] == [512] * 16 and seen[48:64] == [256] * 16 and seen[64:80] == [512] * 16 and seen[80:96] == [256] * 16
+    assert tr.adam_width == 256 and seen[-1] == 256
+    assert abs(tr.adam_tune_ms[512] - 16.0) < 1e-9 and abs(tr.adam_tune_ms[256] - 14.4) < 1e-9
+    tr, seen = drive(1, 200, 32, 2, {512: 1.0, 256: 0.995})           # within the windows' own spread: the default stays
+    assert tr.adam_width == 512
+    tr, seen = drive(1, 200, 32, 2, {512: 0.9, 256: 1.0})
+    assert tr.adam_width == 512
+    tr, seen = drive(5004, 300, 320, 4, {512: 1.0, 256: 0.8})         # resumed at step 5003: starts at the next multiple of 16
+    assert tr.adam_tune[0] == 5008 and tr.adam_width == 256
+    tr = NGPTrainer.__new__(NGPTrainer)                               # a fixed width is never measured
+    tr.adam_width = 384
+    assert tr._adam_width_now(None) == 384
