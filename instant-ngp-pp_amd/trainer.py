@@ -205,6 +205,16 @@ class NGPTrainer:
                                                    priority=int(os.environ.get("NGP_OPT_PRIO", "0")))
                             ) if self.flat_param.is_cuda else None
         self._march_ahead = MarchAhead(self.flat_param.device) if self.flat_param.is_cuda else None
+        if self.flat_param.is_cuda and not serial and not self.sharded and os.environ.get("NGP_SIX_STREAMS", "0") != "1":
+            # Four streams, one per hardware queue of the HIP runtime's default pool: the caller's, the colour forward's, the
+            # optimizer's and the march-ahead's.  The backward's table scatters go on the optimizer stream (clip + Adam follow them
+            # there anyway) and the two heads on the march-ahead stream (idle in the middle of the forward) instead of streams of
+            # their own: with six streams two pairs share a queue, and which pairs depends on the order the streams were created
+            # in — the scatter behind the caller's MLP kernels would cost 0.4 ms per step.  Same speed as the six-stream layout
+            # that happened to come out right (profiles/r03_occupancy_shaping.txt (12); NGP_SIX_STREAMS=1 for the A/B).
+            from . import networks
+            networks._SIDE[self.flat_param.device.index] = self._opt_stream
+            networks._HEADS[self.flat_param.device.index] = self._march_ahead.stream
 
     # ------------------------------------------------------------------ flat parameter store
     def _flatten(self):
